@@ -1,0 +1,170 @@
+/* C ABI of libvitpose_hip.so: the gfx950 (MI355X) kernels behind the ViTPose hot path.
+ *
+ * The reference (MiraPurkrabek/ViTPose) has no native code: every op on the path is a
+ * stock PyTorch/ATen call.  Each entry point below therefore cites the reference
+ * *Python* op it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated,
+ *     freed or synchronised here (safe under HIP graph capture);
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream;
+ *   - return 0 on success, VP_ERR_ARG (-1) for a rejected argument, VP_ERR_UNSUPPORTED (-2)
+ *     for a shape outside the compiled set, or a positive hipError_t from the launch;
+ *   - "bf16" is the 16-bit brain-float bit pattern (torch.bfloat16), "f32" IEEE float;
+ *   - token-major activations: row m = b * tokens + n, columns = channels.
+ */
+#ifndef VITPOSE_HIP_H
+#define VITPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef void* vp_stream_t;
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t vp_stream_t;
+#endif
+
+#define VP_ABI_VERSION 1
+int vp_abi_version(void);
+/* gfx target the library was compiled for, e.g. "gfx950". */
+const char* vp_build_arch(void);
+
+/* ------------------------------------------------------------------ GEMM --------
+ * C[i][j] = sum_k X[i][k] * Y[j][k], bf16 operands, f32 accumulation on MFMA.
+ * Replaces nn.Linear forward/backward on the path: Attention.qkv / .proj
+ * (mmpose/models/backbones/vit.py:93,96,101,112), Mlp.fc1 / .fc2 (vit.py:66-74), and, via
+ * im2col / sub-pixel views, PatchEmbed.proj (vit.py:157,161) and the head's
+ * ConvTranspose2d / Conv2d (mmpose/models/heads/topdown_heatmap_simple_head.py:132-139,323-332).
+ *   x_kmajor / y_kmajor = 0: operand stored P[r*ld + k];  1: stored P[k*ld + r].
+ */
+enum {
+    VP_EPI_BF16 = 0,       /* out(bf16) = acc*colscale + bias                                   */
+    VP_EPI_GELU = 1,       /* out2(bf16, optional) = u = acc + bias; out(bf16) = gelu_erf(u)    */
+    VP_EPI_RESID_F32 = 2,  /* out(f32) = resid + rowscale[i/rows_per_scale]*(acc+bias) + pos[i%pos_rows] */
+    VP_EPI_DGELU = 3,      /* out(bf16) = acc * gelu_erf'(aux(bf16))                            */
+    VP_EPI_ATOMIC_F32 = 4, /* out(f32) += acc   (atomic; split_k >= 1)                          */
+    VP_EPI_F32 = 5,        /* out(f32) = acc + bias                                             */
+    VP_EPI_SCALE_RELU = 6, /* out(bf16) = relu(acc*colscale + bias)                             */
+    VP_EPI_DRELU = 7       /* out(bf16) = acc * (aux(bf16) > 0)                                 */
+};
+
+typedef struct vp_gemm_args {
+    int M, N, K;
+    const void* x; int ldx; int x_kmajor;
+    const void* y; int ldy; int y_kmajor;
+    int epilogue;
+    void* out; int ldo;          /* ldo also strides resid / pos / out2 */
+    void* out2;
+    const float* bias;           /* [N] or NULL */
+    const float* colscale;       /* [N] or NULL */
+    const float* resid;          /* [M][ldo] f32 or NULL */
+    const float* rowscale;       /* [ceil(M/rows_per_scale)] or NULL (DropPath per-sample scale) */
+    int rows_per_scale;
+    const void* aux; int ldaux;  /* [M][ldaux] bf16 for DGELU / DRELU */
+    const float* pos;            /* [pos_rows][ldo] f32 or NULL */
+    int pos_rows;
+    int split_k;                 /* ATOMIC_F32 only: number of K slices (grid.y) */
+    /* optional output row remap (sub-pixel phases of a transposed conv): when out_row_div > 0,
+     * row i of C is stored at row (i / div) * hi + (i % div) * lo + off of out / out2. */
+    int out_row_div, out_row_hi, out_row_lo, out_row_off;
+} vp_gemm_args;
+
+int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);
+
+/* dtype tags for the layout/cast helpers */
+enum { VP_F32 = 0, VP_BF16 = 1 };
+
+/* ------------------------------------------------------------- LayerNorm --------
+ * nn.LayerNorm(E, eps=1e-6) over the channel axis of token-major x [M][E] f32
+ * (Block.norm1 / norm2, vit.py:125,133,138-139; ViT.last_norm, vit.py:242,328).
+ * fwd: y (bf16 and/or f32) = (x - mean) * rstd * gamma + beta; mean/rstd [M] saved if non-NULL.
+ * bwd: dx = dres + dLN(dy); dxb (bf16) = rowscale[m / rows_per_scale] * dx;
+ *      dgamma/dbeta/dcolsum [E] are ACCUMULATED (f32 atomics); dcolsum = column sum of dxb
+ *      (the bias gradient of the Linear whose output feeds this residual stream). */
+int vp_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                     float* mean, float* rstd, int M, int E, float eps, vp_stream_t stream);
+int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, const float* dres, float* dx, void* dxb_bf16,
+                     const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
+                     float* dcolsum, int M, int E, vp_stream_t stream);
+
+/* ------------------------------------------------------------- Attention --------
+ * Attention.forward core, vit.py:102-111: softmax(q k^T * scale) v over all `tokens`
+ * keys of one image, per head.  qkv = packed [B*tokens][3*H*head_dim] bf16 exactly as
+ * the qkv Linear emits it (q | k | v, head-major inside each); out = [B*tokens][H*head_dim]
+ * bf16 (the layout `.transpose(1, 2).reshape(B, N, -1)` produces); lse [B*H][tokens] f32 =
+ * log-sum-exp of the scaled scores (saved for backward).  tokens must be 192, head_dim 32 or 64.
+ * bwd writes dqkv in the packed layout (every element written once). */
+int vp_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int head_dim, int tokens,
+                     float scale, vp_stream_t stream);
+int vp_attention_bwd(const void* qkv, const void* out_fwd, const void* dout, const float* lse, void* dqkv,
+                     int B, int H, int head_dim, int tokens, float scale, vp_stream_t stream);
+
+/* ---------------------------------------------------- layout / data movement ---- */
+/* PatchEmbed.proj as a GEMM (vit.py:157,161): rows of the NCHW f32 image gathered into
+ * col [B*Hp*Wp][C*patch*patch] bf16, k = (c, ky, kx) = the flattened conv weight order. */
+int vp_patch_im2col(const float* img, void* col_bf16, int B, int C, int H, int W, int patch, int stride,
+                    int pad, vp_stream_t stream);
+/* out[i0][i1][i2][i3] (contiguous) = (cast) in[i0*s0 + i1*s1 + i2*s2 + i3*s3]: weight re-layouts,
+ * NCHW <-> token-major permutes (vit.py:164,330). */
+int vp_strided_cast(const void* in, int in_dtype, void* out, int out_dtype, const int dims[4],
+                    const long strides[4], vp_stream_t stream);
+/* out[N] += column sums of a bf16 [M][N] matrix (bias gradients). */
+int vp_colsum_bf16(const void* a, float* out, int M, int N, int lda, vp_stream_t stream);
+/* out[n] = sum_b x[b][n] (pos_embed gradient, vit.py:320). */
+int vp_batch_sum_f32(const float* x, float* out, int B, size_t n, vp_stream_t stream);
+/* ConvTranspose2d(k=4, s=2, p=1) (topdown_heatmap_simple_head.py:323-332) as 4 sub-pixel GEMMs:
+ * col[(b,y,x)][t*C + c] = in[b][y+dy][x+dx][c] for output parity (py, px), channels-last bf16. */
+int vp_deconv_phase_im2col(const void* in, void* col, int B, int H, int W, int C, int py, int px,
+                           vp_stream_t stream);
+/* its backward: g[(b,iy,ix)][(ky*4+kx)*C + c] = dout[b][2iy-1+ky][2ix-1+kx][c] (H, W = input grid). */
+int vp_deconv_out_gather16(const void* dout, void* g, int B, int H, int W, int C, vp_stream_t stream);
+int vp_cast_f32_bf16(const float* x, void* y, size_t n, vp_stream_t stream);
+
+/* ------------------------------------------------------------- BatchNorm --------
+ * nn.BatchNorm2d(256) + ReLU of the deconv stack (topdown_heatmap_simple_head.py:333-334) on
+ * channels-last bf16 z [M][C].  stats: sums[0:C] += sum z, sums[C:2C] += sum z^2.
+ * finalize: training (sums != NULL) -> batch statistics, running stats updated (momentum,
+ * unbiased var); eval (sums == NULL) -> running statistics.  scale/shift fold BN into y = z*scale+shift. */
+int vp_bn_stats(const void* z, float* sums, int M, int C, vp_stream_t stream);
+int vp_bn_finalize(const float* sums, int M, int C, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                   float* shift, float* save_mean, float* save_invstd, vp_stream_t stream);
+int vp_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift, int M, int C,
+                     vp_stream_t stream);
+/* g = gradient wrt the BN output with the ReLU mask applied; dgamma/dbeta ACCUMULATE. */
+int vp_bn_bwd(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+              float* dgamma, float* dbeta, void* dz, int M, int C, vp_stream_t stream);
+
+/* ------------------------------------------------------------------ Loss --------
+ * JointsMSELoss.forward (mmpose/models/losses/mse_loss.py:24-44) fused with its gradient and the
+ * channels-last -> NCHW copy of the heatmaps.  heat [B*HW][ldh] f32 (first K columns valid);
+ * heat_nchw [B][K][HW] f32 (optional); target NCHW f32 and tw [B][K] (NULL = no loss);
+ * *loss += loss value; dheat [B*HW][ldh] bf16 = dL/dheat (optional). */
+int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, const float* target, const float* tw,
+                    float* loss, void* dheat, int B, int K, int HW, float loss_weight, vp_stream_t stream);
+/* _get_max_preds (mmpose/core/evaluation/top_down_eval.py:63-95): first arg-max of each row. */
+int vp_argmax_rows(const float* x, int rows, int L, int* idx, float* val, vp_stream_t stream);
+
+/* ------------------------------------------------------------- Optimizer --------
+ * Gradient clipping (mmcv OptimizerHook grad_clip max_norm, configs/.../ViTPose_base_coco_256x192.py:30)
+ * and torch.optim.AdamW over flat f32 buffers; per-chunk lr scale / weight decay carry the
+ * layer-decay groups of mmcv_custom/layer_decay_optimizer_constructor.py:39-78.
+ * *out += sum x^2.  adamw: grads are multiplied by grad_scale * min(1, max_norm / (sqrt(*gnorm_sq) *
+ * grad_scale + 1e-6)) on the fly; p_bf16 (optional) receives the bf16 copy of the new weights. */
+int vp_sumsq_f32(const float* x, size_t n, float* out, vp_stream_t stream);
+int vp_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const long* chunk_start,
+                  const int* chunk_len, const float* chunk_lr_scale, const float* chunk_wd, int nchunks,
+                  float lr, float beta1, float beta2, float eps, int step, const float* gnorm_sq,
+                  float max_norm, float grad_scale, vp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITPOSE_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libvitpose_hip.so (the C ABI declared in include/vitpose_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or does not
+export a symbol, importing this module's `lib()` raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
+
+VP_EPI_BF16, VP_EPI_GELU, VP_EPI_RESID_F32, VP_EPI_DGELU = 0, 1, 2, 3
+VP_EPI_ATOMIC_F32, VP_EPI_F32, VP_EPI_SCALE_RELU, VP_EPI_DRELU = 4, 5, 6, 7
+VP_F32, VP_BF16 = 0, 1
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ('M', c_int), ('N', c_int), ('K', c_int),
+        ('x', c_void_p), ('ldx', c_int), ('x_kmajor', c_int),
+        ('y', c_void_p), ('ldy', c_int), ('y_kmajor', c_int),
+        ('epilogue', c_int),
+        ('out', c_void_p), ('ldo', c_int),
+        ('out2', c_void_p),
+        ('bias', c_void_p), ('colscale', c_void_p), ('resid', c_void_p),
+        ('rowscale', c_void_p), ('rows_per_scale', c_int),
+        ('aux', c_void_p), ('ldaux', c_int),
+        ('pos', c_void_p), ('pos_rows', c_int),
+        ('split_k', c_int),
+        ('out_row_div', c_int), ('out_row_hi', c_int), ('out_row_lo', c_int), ('out_row_off', c_int),
+    ]
+
+
+P = c_void_p
+# name -> argtypes (the trailing stream argument included); every function returns int
+SIGNATURES = {
+    'vp_gemm_bf16': [POINTER(GemmArgs), P],
+    'vp_layernorm_fwd': [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
+    'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P],
+    'vp_attention_fwd': [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    'vp_attention_bwd': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    'vp_patch_im2col': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    'vp_strided_cast': [P, c_int, P, c_int, POINTER(c_int * 4), POINTER(c_long * 4), P],
+    'vp_colsum_bf16': [P, P, c_int, c_int, c_int, P],
+    'vp_batch_sum_f32': [P, P, c_int, c_size_t, P],
+    'vp_deconv_phase_im2col': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    'vp_deconv_out_gather16': [P, P, c_int, c_int, c_int, c_int, P],
+    'vp_cast_f32_bf16': [P, P, c_size_t, P],
+    'vp_bn_stats': [P, P, c_int, c_int, P],
+    'vp_bn_finalize': [P, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P],
+    'vp_bn_apply_relu': [P, P, P, P, c_int, c_int, P],
+    'vp_bn_bwd': [P, P, P, P, P, P, P, P, c_int, c_int, P],
+    'vp_heatmap_loss': [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
+    'vp_argmax_rows': [P, c_int, c_int, P, P, P],
+    'vp_sumsq_f32': [P, c_size_t, P, P],
+    'vp_adamw_step': [P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_float, c_int, P,
+                      c_float, c_float, P],
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library once; raise loudly when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: build it with `make -C vitpose_amd/csrc` (or '
+            '`python -c "import __graft_entry__ as g; g.build()"`). There is no CPU fallback.')
+    L = ctypes.CDLL(LIB_PATH)
+    L.vp_abi_version.restype = c_int
+    L.vp_build_arch.restype = ctypes.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    return ['vp_abi_version', 'vp_build_arch'] + list(SIGNATURES)

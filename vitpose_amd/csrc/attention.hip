@@ -1,0 +1,299 @@
+// Fused global multi-head self-attention over the 192 tokens of a 256x192 crop
+// (forward and backward), one 256-thread workgroup per (image, head).
+//
+// Input is the packed qkv activation [B*192][3E] (columns q | k | v, each head-major),
+// exactly as the qkv Linear writes it; output is token-major [B*192][E].  No
+// [B,h,N,d] permutes are materialised and the 192x192 score matrix never leaves
+// registers: K/V (and Q/dO in backward) sit in LDS, each wave owns 16 query (or key)
+// rows at a time and holds a full 192-wide score row, so softmax is single pass.
+//
+// MFMA orientation: scores are computed "key on the accumulator row, query on the
+// lane" (D = K * Q^T), so the probabilities a lane holds are already the B operand of
+// the P*V product (k order inside a 32-step = {4g+e, 16+4g+e}, matched by the
+// transposed LDS reads of V); nothing crosses lanes except the 2-step row reduction.
+#include "common.h"
+#include "vitpose_hip.h"
+
+namespace {
+
+constexpr int NTOK = 192;
+
+// One LDS image serves ds_read_b128 row reads and ds_read_b64_tr_b16 transposed
+// reads: rows of D bf16, 32-byte units XOR-swizzled by a row key so that both the 8
+// rows of a transposed read and the 16 rows of a row read fall on distinct banks.
+template <int D>
+struct Img {
+    static constexpr int P = D * 2;          // row pitch in bytes
+    static constexpr int U = D / 16;         // 32-byte units per row
+    static constexpr int R = 256 / P;        // rows per 256-byte bank row
+    static constexpr int BYTES = NTOK * P;
+    __device__ static __forceinline__ int key(int row) { return (row / R) % U; }
+    __device__ static __forceinline__ int off16(int row, int c16) {  // 16-byte chunk c16 of a row
+        return row * P + ((((c16 >> 1) ^ key(row)) << 5) | ((c16 & 1) << 4));
+    }
+    // row-read fragment: rows [r0, r0+16), reduction step s (32 wide): lane -> row r0+li, chunk 4s+g
+    __device__ static __forceinline__ bf16x8 rows(const char* img, int r0, int s, int lane) {
+        return *reinterpret_cast<const bf16x8*>(img + off16(r0 + (lane & 15), 4 * s + (lane >> 4)));
+    }
+    // transposed fragment for the reduction over ROWS: 32-row step rs, 16-column unit dt.
+    // element 4h+e of lane (g, li) = img[32 rs + 16 h + 4 g + e][16 dt + li]
+    __device__ static __forceinline__ bf16x8 cols(const char* img, int rs, int dt, int lane) {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int ra = 32 * rs + 4 * g + q, rb = ra + 16;
+        bf16x4 lo = lds_read_tr(img + ra * P + ((dt ^ key(ra)) << 5) + (p << 3));
+        bf16x4 hi = lds_read_tr(img + rb * P + ((dt ^ key(rb)) << 5) + (p << 3));
+        return cat8(lo, hi);
+    }
+    // cooperative fill from a strided global matrix (row stride ld elements)
+    __device__ static __forceinline__ void fill(char* img, const bf16* src, size_t ld, int tid) {
+        constexpr int CH = D / 8;
+        for (int idx = tid; idx < NTOK * CH; idx += 256) {
+            const int row = idx / CH, c = idx % CH;
+            *reinterpret_cast<uint4*>(img + off16(row, c)) =
+                *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
+        }
+    }
+};
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = (bf16)a[i]; r[4 + i] = (bf16)b[i]; }
+    return r;
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                          float* __restrict__ lse, int H, int E, float scale) {
+    using I = Img<D>;
+    __shared__ __attribute__((aligned(16))) char lds[2 * I::BYTES];
+    char* kimg = lds;
+    char* vimg = lds + I::BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const size_t ld = 3 * (size_t)E;
+    const bf16* base = qkv + (size_t)b * NTOK * ld + h * D;
+    I::fill(kimg, base + E, ld, tid);
+    I::fill(vimg, base + 2 * E, ld, tid);
+    __syncthreads();
+    const float c = scale * 1.44269504088896340736f;
+    constexpr int KS = D / 32;
+#pragma unroll 1
+    for (int qt = 0; qt < 3; ++qt) {
+        const int q0 = wave * 48 + qt * 16;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)(q0 + li) * ld + 32 * s + 8 * g);
+        f32x4 sc[12];
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt) {
+            sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(kimg, 16 * kt, s, lane), qf[s], sc[kt], 0, 0, 0);
+        }
+        // sc[kt][r] = <q(q0+li), k(16kt+4g+r)>; softmax over keys = over kt, r and the 4 lane groups
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        const float mc = m * c;
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[kt][r] = __builtin_amdgcn_exp2f(sc[kt][r] * c - mc);
+                l += sc[kt][r];
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (lse && g == 0) lse[(size_t)blockIdx.x * NTOK + q0 + li] = m * scale + __logf(l);
+        const float inv = 1.f / l;
+        f32x4 o[D / 16];
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 pb = pack8(sc[2 * ks], sc[2 * ks + 1]);
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(vimg, ks, dt, lane), pb, o[dt], 0, 0, 0);
+        }
+        bf16* orow = out + ((size_t)b * NTOK + q0 + li) * E + h * D;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt)
+            *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) =
+                pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+}
+
+// Backward: recompute P from the forward's log-sum-exp.  Phase A (a wave owns 16
+// queries): S, dP -> dS -> dQ.  Phase B (a wave owns 16 keys): S^T, dP^T -> P^T, dS^T
+// -> dV, dK.  Every reduction is wave-local, so nothing but the four input tiles, the
+// lse and delta vectors goes through LDS, and dq/dk/dv are written exactly once.
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd,
+                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                          bf16* __restrict__ dqkv, int H, int E, float scale) {
+    using I = Img<D>;
+    __shared__ __attribute__((aligned(16))) char lds[4 * I::BYTES + 2 * NTOK * 4];
+    char* qimg = lds;
+    char* kimg = lds + I::BYTES;
+    char* vimg = lds + 2 * I::BYTES;
+    char* dimg = lds + 3 * I::BYTES;
+    float* s_lse = reinterpret_cast<float*>(lds + 4 * I::BYTES);
+    float* s_del = s_lse + NTOK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const size_t ld = 3 * (size_t)E;
+    const bf16* base = qkv + (size_t)b * NTOK * ld + h * D;
+    const bf16* dob = dout + (size_t)b * NTOK * E + h * D;
+    const bf16* ofb = o_fwd + (size_t)b * NTOK * E + h * D;
+    I::fill(qimg, base, ld, tid);
+    I::fill(kimg, base + E, ld, tid);
+    I::fill(vimg, base + 2 * E, ld, tid);
+    I::fill(dimg, dob, (size_t)E, tid);
+    const float LOG2E = 1.44269504088896340736f;
+    if (tid < NTOK) {
+        float d = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < D / 8; ++ch) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(dob + (size_t)tid * E + 8 * ch);
+            const bf16x8 f = *reinterpret_cast<const bf16x8*>(ofb + (size_t)tid * E + 8 * ch);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += (float)a[j] * (float)f[j];
+        }
+        s_del[tid] = d;
+        s_lse[tid] = lse[(size_t)blockIdx.x * NTOK + tid] * LOG2E;
+    }
+    __syncthreads();
+    const float c = scale * LOG2E;
+    constexpr int KS = D / 32;
+    bf16* dq_base = dqkv + (size_t)b * NTOK * ld + h * D;
+
+    // ---------------- phase A: dQ ----------------
+#pragma unroll 1
+    for (int qt = 0; qt < 3; ++qt) {
+        const int q0 = wave * 48 + qt * 16;
+        bf16x8 qf[KS], df[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = I::rows(qimg, q0, s, lane);
+            df[s] = I::rows(dimg, q0, s, lane);
+        }
+        const float my_lse = s_lse[q0 + li], my_del = s_del[q0 + li];
+        f32x4 ds[12];
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt) {
+            f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, pv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(kimg, 16 * kt, s, lane), qf[s], sv, 0, 0, 0);
+                pv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(vimg, 16 * kt, s, lane), df[s], pv, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(sv[r] * c - my_lse) * (pv[r] - my_del);
+        }
+        f32x4 o[D / 16];
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 sb = pack8(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(kimg, ks, dt, lane), sb, o[dt], 0, 0, 0);
+        }
+        bf16* row = dq_base + (size_t)(q0 + li) * ld;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt)
+            *reinterpret_cast<bf16x4*>(row + 16 * dt + 4 * g) =
+                pack4(o[dt][0] * scale, o[dt][1] * scale, o[dt][2] * scale, o[dt][3] * scale);
+    }
+
+    // ---------------- phase B: dK, dV ----------------
+#pragma unroll 1
+    for (int kt = 0; kt < 3; ++kt) {
+        const int k0 = wave * 48 + kt * 16;
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[s] = I::rows(kimg, k0, s, lane);
+            vf[s] = I::rows(vimg, k0, s, lane);
+        }
+        f32x4 dv[D / 16], dk[D / 16];
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qs = 0; qs < 6; ++qs) {
+            f32x4 pp[2], dd[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int qt = 2 * qs + hh;
+                f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, pv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(qimg, 16 * qt, s, lane), kf[s], sv, 0, 0, 0);
+                    pv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(dimg, 16 * qt, s, lane), vf[s], pv, 0, 0, 0);
+                }
+                // sv[r] = <q(16qt+4g+r), k(k0+li)>
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(s_del + 16 * qt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pp[hh][r] = __builtin_amdgcn_exp2f(sv[r] * c - ls[r]);
+                    dd[hh][r] = pp[hh][r] * (pv[r] - dl[r]);
+                }
+            }
+            const bf16x8 pb = pack8(pp[0], pp[1]);
+            const bf16x8 sb = pack8(dd[0], dd[1]);
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(dimg, qs, dt, lane), pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(qimg, qs, dt, lane), sb, dk[dt], 0, 0, 0);
+            }
+        }
+        bf16* row = dq_base + (size_t)(k0 + li) * ld;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            *reinterpret_cast<bf16x4*>(row + E + 16 * dt + 4 * g) =
+                pack4(dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale);
+            *reinterpret_cast<bf16x4*>(row + 2 * E + 16 * dt + 4 * g) = pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vp_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int head_dim, int tokens,
+                                float scale, hipStream_t stream) {
+    VP_CHECK_ARG(qkv && out && B > 0 && H > 0);
+    if (tokens != NTOK) return VP_ERR_UNSUPPORTED;
+    const int E = H * head_dim;
+    dim3 grid(B * H), block(256);
+    switch (head_dim) {
+        case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, stream, (const bf16*)qkv, (bf16*)out, lse, H, E, scale); break;
+        case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, stream, (const bf16*)qkv, (bf16*)out, lse, H, E, scale); break;
+        default: return VP_ERR_UNSUPPORTED;
+    }
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_attention_bwd(const void* qkv, const void* out_fwd, const void* dout, const float* lse, void* dqkv,
+                                int B, int H, int head_dim, int tokens, float scale, hipStream_t stream) {
+    VP_CHECK_ARG(qkv && out_fwd && dout && lse && dqkv && B > 0 && H > 0);
+    if (tokens != NTOK) return VP_ERR_UNSUPPORTED;
+    const int E = H * head_dim;
+    dim3 grid(B * H), block(256);
+    switch (head_dim) {
+        case 32: hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, 0, stream, (const bf16*)qkv, (const bf16*)out_fwd, (const bf16*)dout, lse, (bf16*)dqkv, H, E, scale); break;
+        case 64: hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, 0, stream, (const bf16*)qkv, (const bf16*)out_fwd, (const bf16*)dout, lse, (bf16*)dqkv, H, E, scale); break;
+        default: return VP_ERR_UNSUPPORTED;
+    }
+    VP_LAUNCH_RET();
+}

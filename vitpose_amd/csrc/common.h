@@ -1,0 +1,72 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the ViTPose hot path.
+// Wavefront = 64 lanes; MFMA fragments follow the v_mfma_f32_16x16x32_bf16 lane maps:
+//   A operand: lane l holds A[row l&15][k = 8*(l>>4) + 0..7]
+//   B operand: lane l holds B[k = 8*(l>>4) + 0..7][col l&15]
+//   C/D:       lane l holds D[row 4*(l>>4) + r][col l&15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define VP_WAVE 64
+
+#define VP_OK 0
+#define VP_ERR_ARG (-1)     // bad argument (shape / alignment / null pointer)
+#define VP_ERR_UNSUPPORTED (-2)
+
+#define VP_CHECK_ARG(cond) do { if (!(cond)) return VP_ERR_ARG; } while (0)
+#define VP_LAUNCH_RET() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? VP_OK : (int)e_; } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }  // round-to-nearest-even, NaN-preserving
+
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d;
+    return r;
+}
+
+__device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) {
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Transposed LDS read: per 16-lane group a 4-row x 16-column block of 16-bit
+// elements comes back column-major (lane i of the group gets column i of the 4 rows).
+// Lane 4q+p of the group must pass the address of row q, columns 4p..4p+3.
+__device__ __forceinline__ bf16x4 lds_read_tr(const char* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (bf16x4 __attribute__((address_space(3)))*)(lds_ptr));
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (its L2),
+// so give each of the 8 residue classes one contiguous chunk of the tile order.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

@@ -1,0 +1,199 @@
+// HBM-bound data-movement kernels around the GEMMs of the ViTPose hot path:
+// im2col views (patch embedding, sub-pixel transposed conv), layout/dtype changes,
+// column sums.  All are pure streaming kernels (every byte read/written once,
+// 8-16 B per lane where the layout allows).
+#include "common.h"
+#include "vitpose_hip.h"
+
+namespace {
+
+// ---- patch embedding im2col: NCHW f32 image -> [B*Hp*Wp][C*p*p] bf16 rows (k = (c, ky, kx)) ----
+// One thread per 8 consecutive kx of one (token, c, ky): 8 pixels of one image row.
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* __restrict__ img, bf16* __restrict__ col,
+                                                           int B, int C, int H, int W, int Hp, int Wp, int p,
+                                                           int stride, int pad) {
+    const int K = C * p * p;
+    const int chunks = K >> 3;
+    const size_t total = (size_t)B * Hp * Wp * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t tok = i / chunks;
+        const int k = ch << 3;
+        const int c = k / (p * p), ky = (k / p) % p, kx0 = k % p;
+        const int px = (int)(tok % Wp), py = (int)((tok / Wp) % Hp), b = (int)(tok / ((size_t)Wp * Hp));
+        const int y = py * stride - pad + ky;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int x = px * stride - pad + kx0 + j;
+            const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+            o[j] = (bf16)(ok ? img[(((size_t)b * C + c) * H + y) * W + x] : 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(col + tok * K + k) = o;
+    }
+}
+
+// ---- generic 4-D strided gather + cast: out[i0][i1][i2][i3] (contiguous) = in[sum i_k * s_k] ----
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void strided_cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int d0,
+                                                           int d1, int d2, int d3, long s0, long s1, long s2, long s3) {
+    const size_t total = (size_t)d0 * d1 * d2 * d3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int i3 = (int)(i % d3);
+        size_t r = i / d3;
+        const int i2 = (int)(r % d2);
+        r /= d2;
+        const int i1 = (int)(r % d1);
+        const int i0 = (int)(r / d1);
+        out[i] = (TO)(float)in[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+    }
+}
+
+// ---- column sums of a bf16 [M][N] matrix into f32 [N] (atomic accumulate) ----
+// block = 256 threads = 32 column-chunks (8 cols) x 8 row lanes; grid.x tiles columns, grid.y rows.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ a, float* __restrict__ out, int M, int N,
+                                                     int lda, int rows_per_block) {
+    __shared__ float red[8][256 + 8];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + cx) * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        for (int r = r0 + ry; r < r1; r += 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + (size_t)r * lda + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ry][cx * 8 + j] = s[j];
+    __syncthreads();
+    const int c = threadIdx.x;  // 256 columns of this block
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    const int gc = blockIdx.x * 256 + c;
+    if (gc < N) atomicAdd(out + gc, t);
+}
+
+// ---- sum over the batch of token-major f32 [B][T*E] -> [T*E] (pos_embed gradient) ----
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
+                                                        size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) s += *reinterpret_cast<const f32x4*>(x + (size_t)b * n + i);
+    *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+// ---- sub-pixel view of a k4/s2/p1 transposed conv, output parity (py, px) ----
+// col[(b,y,x)][t*C + c] = in[b][y + dy(py,ty)][x + dx(px,tx)][c]  (0 outside), t = ty*2 + tx,
+// dy(0,{0,1}) = {0,-1}, dy(1,{0,1}) = {+1,0}; the matching kernel taps are ky(0,.) = {1,3}, ky(1,.) = {0,2}.
+__global__ __launch_bounds__(256) void deconv_phase_im2col_kernel(const bf16* __restrict__ in, bf16* __restrict__ col,
+                                                                  int B, int H, int W, int C, int py, int px) {
+    const int chunks = (4 * C) >> 3;
+    const size_t total = (size_t)B * H * W * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t pix = i / chunks;
+        const int k = ch << 3, t = k / C, c = k % C;
+        const int ty = t >> 1, tx = t & 1;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+        const int yy = y + (py ? 1 - ty : -ty), xx = x + (px ? 1 - tx : -tx);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            v = *reinterpret_cast<const uint4*>(in + (((size_t)b * H + yy) * W + xx) * C + c);
+        *reinterpret_cast<uint4*>(col + pix * (size_t)(4 * C) + k) = v;
+    }
+}
+
+// ---- 16-tap gather of the transposed conv's OUTPUT grid around each INPUT pixel ----
+// G[(b,iy,ix)][(ky*4+kx)*C + c] = dout[b][2iy-1+ky][2ix-1+kx][c]  (0 outside); H, W = input grid.
+// Both the data gradient (G x Wd^T) and the weight gradient (in^T x G) read it.
+__global__ __launch_bounds__(256) void deconv_out_gather16_kernel(const bf16* __restrict__ dout, bf16* __restrict__ g,
+                                                                  int B, int H, int W, int C) {
+    const int chunks = (16 * C) >> 3;
+    const size_t total = (size_t)B * H * W * chunks;
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t pix = i / chunks;
+        const int k = ch << 3, t = k / C, c = k % C;
+        const int ky = t >> 2, kx = t & 3;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+        const int oy = 2 * y - 1 + ky, ox = 2 * x - 1 + kx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo)
+            v = *reinterpret_cast<const uint4*>(dout + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
+        *reinterpret_cast<uint4*>(g + pix * (size_t)(16 * C) + k) = v;
+    }
+}
+
+inline int grid_for(size_t work_items) {
+    size_t g = (work_items + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g ? g : 1));
+}
+
+}  // namespace
+
+extern "C" int vp_patch_im2col(const float* img, void* col_bf16, int B, int C, int H, int W, int patch, int stride,
+                               int pad, hipStream_t stream) {
+    VP_CHECK_ARG(img && col_bf16 && B > 0 && C > 0 && patch % 8 == 0 && stride > 0);
+    const int Hp = (H + 2 * pad - patch) / stride + 1, Wp = (W + 2 * pad - patch) / stride + 1;
+    VP_CHECK_ARG(Hp > 0 && Wp > 0);
+    const size_t total = (size_t)B * Hp * Wp * (C * patch * patch / 8);
+    hipLaunchKernelGGL(patch_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, (bf16*)col_bf16, B, C, H,
+                       W, Hp, Wp, patch, stride, pad);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_strided_cast(const void* in, int in_dtype, void* out, int out_dtype, const int dims[4],
+                               const long strides[4], hipStream_t stream) {
+    VP_CHECK_ARG(in && out && dims && strides);
+    const size_t total = (size_t)dims[0] * dims[1] * dims[2] * dims[3];
+    VP_CHECK_ARG(total > 0);
+    dim3 grid(grid_for(total)), block(256);
+#define VP_SC(TI, TO)                                                                                     \
+    hipLaunchKernelGGL((strided_cast_kernel<TI, TO>), grid, block, 0, stream, (const TI*)in, (TO*)out,    \
+                       dims[0], dims[1], dims[2], dims[3], strides[0], strides[1], strides[2], strides[3])
+    if (in_dtype == VP_F32 && out_dtype == VP_BF16) VP_SC(float, bf16);
+    else if (in_dtype == VP_F32 && out_dtype == VP_F32) VP_SC(float, float);
+    else if (in_dtype == VP_BF16 && out_dtype == VP_F32) VP_SC(bf16, float);
+    else if (in_dtype == VP_BF16 && out_dtype == VP_BF16) VP_SC(bf16, bf16);
+    else return VP_ERR_ARG;
+#undef VP_SC
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_colsum_bf16(const void* a, float* out, int M, int N, int lda, hipStream_t stream) {
+    VP_CHECK_ARG(a && out && M > 0 && N > 0 && N % 8 == 0 && lda % 8 == 0);
+    const int gx = (N + 255) / 256;
+    int gy = (M + 255) / 256;
+    if (gy > 512) gy = 512;
+    const int rpb = (M + gy - 1) / gy;
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)a, out, M, N, lda, rpb);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_batch_sum_f32(const float* x, float* out, int B, size_t n, hipStream_t stream) {
+    VP_CHECK_ARG(x && out && B > 0 && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, x, out, B, n);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_deconv_phase_im2col(const void* in, void* col, int B, int H, int W, int C, int py, int px,
+                                      hipStream_t stream) {
+    VP_CHECK_ARG(in && col && B > 0 && H > 0 && W > 0 && C % 8 == 0 && (py | 1) == 1 && (px | 1) == 1);
+    const size_t total = (size_t)B * H * W * (4 * C / 8);
+    hipLaunchKernelGGL(deconv_phase_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16*)in,
+                       (bf16*)col, B, H, W, C, py, px);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_deconv_out_gather16(const void* dout, void* g, int B, int H, int W, int C, hipStream_t stream) {
+    VP_CHECK_ARG(dout && g && B > 0 && H > 0 && W > 0 && C % 8 == 0);
+    const size_t total = (size_t)B * H * W * (16 * C / 8);
+    hipLaunchKernelGGL(deconv_out_gather16_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16*)dout,
+                       (bf16*)g, B, H, W, C);
+    VP_LAUNCH_RET();
+}

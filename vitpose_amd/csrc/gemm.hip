@@ -1,0 +1,286 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950.
+//
+//   C[i][j] = sum_k X[i][k] * Y[j][k]        i in [0,M), j in [0,N), k in [0,K)
+//
+// X ("row operand") and Y ("column operand") are bf16 and each may be stored
+// reduction-contiguous (P[r*ld + k], "k-contiguous") or reduction-major
+// (P[k*ld + r], "k-major").  That covers the three products of a Linear layer with
+// one kernel body and no transposed copies:
+//   forward  y = x W^T   : X = x  [M][K] k-contig, Y = W  [N][K] k-contig
+//   dgrad    dx = dy W    : X = dy [M][N] k-contig, Y = W  [N][K] k-major
+//   wgrad    dW = dy^T x  : X = dy [M][N] k-major,  Y = x  [M][K] k-major  (split-K + f32 atomics)
+//
+// Tiling: 128x128x64 per 256-thread workgroup, 2x2 waves of 64x64, each wave 4x4
+// v_mfma_f32_16x16x32_bf16 tiles.  Operands are staged global -> registers -> LDS
+// (issue the next tile's loads before the MFMAs of the current one, write them to
+// the other LDS buffer afterwards; one barrier per K step).  LDS images are
+// XOR-swizzled: k-contiguous tiles are read with ds_read_b128 (conflict-free),
+// k-major tiles with ds_read_b64_tr_b16 (hardware transpose, conflict-free).
+// The MFMA A operand is the Y tile and the B operand the X tile, so a lane ends
+// up with 4 consecutive columns of one C row: 8/16-byte epilogue accesses.
+#include "common.h"
+#include "vitpose_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+// 32-byte-unit swizzle key of a k-major tile row (rows 0-3 / 8-11 of a 16-row
+// group must land on 8 distinct 8-bank slots for the transposed read).
+__device__ __forceinline__ int kmaj_key(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+
+struct Operand {
+    const bf16* p;
+    int ld;
+    int rows;  // extent of the non-reduction index
+};
+
+// ---- global -> registers (one 128x64 tile = 4 x 16 B per thread) ----
+template <bool KMAJ>
+__device__ __forceinline__ void load_tile(const Operand& op, int r0, int k0, int tid, uint4 (&v)[4]) {
+    if constexpr (!KMAJ) {
+        const int c = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = r0 + (tid >> 3) + 32 * i;
+            r = r < op.rows ? r : op.rows - 1;  // clamped rows only feed masked outputs
+            v[i] = *reinterpret_cast<const uint4*>(op.p + (size_t)r * op.ld + k0 + c * 8);
+        }
+    } else {
+        const int c = tid & 15;
+        int col = r0 + c * 8;
+        col = col <= op.rows - 8 ? col : op.rows - 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = (tid >> 4) + 16 * i;
+            v[i] = *reinterpret_cast<const uint4*>(op.p + (size_t)(k0 + kr) * op.ld + col);
+        }
+    }
+}
+
+// ---- registers -> LDS (swizzled) ----
+template <bool KMAJ>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const uint4 (&v)[4]) {
+    if constexpr (!KMAJ) {
+        const int c = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ (r & 7)) << 4)) = v[i];
+        }
+    } else {
+        const int c = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = (tid >> 4) + 16 * i;
+            *reinterpret_cast<uint4*>(lds + kr * 256 + (((c >> 1) ^ kmaj_key(kr)) << 5) + ((c & 1) << 4)) = v[i];
+        }
+    }
+}
+
+// ---- LDS -> MFMA fragment: rows [rbase, rbase+16) of the tile, k sub-step s (32 wide) ----
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int s, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    if constexpr (!KMAJ) {
+        const int r = rbase + li;
+        return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((((s << 2) + g) ^ (r & 7)) << 4));
+    } else {
+        const int q = li >> 2, p = li & 3, unit = rbase >> 4;
+        const int kr0 = 32 * s + 8 * g + q, kr1 = kr0 + 4;
+        bf16x4 lo = lds_read_tr(lds + kr0 * 256 + ((unit ^ kmaj_key(kr0)) << 5) + (p << 3));
+        bf16x4 hi = lds_read_tr(lds + kr1 * 256 + ((unit ^ kmaj_key(kr1)) << 5) + (p << 3));
+        return cat8(lo, hi);
+    }
+}
+
+struct Epi {
+    int kind;
+    void* out; int ldo;
+    void* out2;
+    const float* bias;
+    const float* resid;
+    const float* rowscale; int rows_per_scale;
+    const void* aux; int ldaux;
+    const float* pos; int pos_rows;
+    const float* colscale;
+    int row_div, row_hi, row_lo, row_off;  // out row = (i / div) * hi + (i % div) * lo + off when div > 0
+};
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const Epi& e, int row, int col, f32x4 v) {
+    // (row, col..col+3) of C; caller guarantees row < M and col + 3 < N
+    const size_t orow = e.row_div > 0 ? (size_t)(row / e.row_div) * e.row_hi + (row % e.row_div) * e.row_lo + e.row_off
+                                      : (size_t)row;
+    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
+        if (e.colscale) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(e.colscale + col);
+            v *= s;
+        }
+        if (e.bias) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + col);
+            v += b;
+        }
+        if constexpr (EPI == VP_EPI_GELU) {
+            if (e.out2)
+                *reinterpret_cast<bf16x4*>((bf16*)e.out2 + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+        if constexpr (EPI == VP_EPI_SCALE_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        *reinterpret_cast<bf16x4*>((bf16*)e.out + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == VP_EPI_RESID_F32) {
+        // out = resid + rowscale[row / rows_per_scale] * (acc + bias) (+ pos[row % pos_rows])
+        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + col);
+        if (e.rowscale) v *= e.rowscale[row / e.rows_per_scale];
+        if (e.resid) v += *reinterpret_cast<const f32x4*>(e.resid + (size_t)row * e.ldo + col);
+        if (e.pos) v += *reinterpret_cast<const f32x4*>(e.pos + (size_t)(row % e.pos_rows) * e.ldo + col);
+        *reinterpret_cast<f32x4*>((float*)e.out + orow * e.ldo + col) = v;
+    } else if constexpr (EPI == VP_EPI_DGELU) {
+        const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)e.aux + (size_t)row * e.ldaux + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+        *reinterpret_cast<bf16x4*>((bf16*)e.out + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == VP_EPI_ATOMIC_F32) {
+        float* o = (float*)e.out + orow * e.ldo + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(o + r, v[r]);
+    } else if constexpr (EPI == VP_EPI_F32) {
+        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + col);
+        *reinterpret_cast<f32x4*>((float*)e.out + orow * e.ldo + col) = v;
+    } else if constexpr (EPI == VP_EPI_DRELU) {
+        // out = acc * (aux > 0)   (aux = the ReLU's bf16 output)
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>((const bf16*)e.aux + (size_t)row * e.ldaux + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)a[r] > 0.f ? v[r] : 0.f;
+        *reinterpret_cast<bf16x4*>((bf16*)e.out + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <bool XKMAJ, bool YKMAJ, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y, int M, int N, int K,
+                                                           int tiles_n, int ntiles, int ksplit_tiles, Epi e) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // tile order: the N tiles of one 128-row panel are consecutive, and each XCD
+    // (blocks congruent mod 8) gets a contiguous chunk of that order
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int i0 = (t / tiles_n) * BM, j0 = (t % tiles_n) * BN;
+    const int nk_all = K / BK;
+    const int kt0 = blockIdx.y * ksplit_tiles;
+    const int kt1 = min(nk_all, kt0 + ksplit_tiles);
+    if (kt0 >= kt1) return;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 xr[4], yr[4];
+    load_tile<XKMAJ>(X, i0, kt0 * BK, tid, xr);
+    load_tile<YKMAJ>(Y, j0, kt0 * BK, tid, yr);
+    store_tile<XKMAJ>(lds[0][0], tid, xr);
+    store_tile<YKMAJ>(lds[0][1], tid, yr);
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) {
+            load_tile<XKMAJ>(X, i0, (kt + 1) * BK, tid, xr);
+            load_tile<YKMAJ>(Y, j0, (kt + 1) * BK, tid, yr);
+        }
+        const char* lx = lds[cur][0];
+        const char* ly = lds[cur][1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 xf[4], yf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xf[a] = read_frag<XKMAJ>(lx, wm * 64 + a * 16, s, lane);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) yf[b] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<XKMAJ>(lds[cur ^ 1][0], tid, xr);
+            store_tile<YKMAJ>(lds[cur ^ 1][1], tid, yr);
+        }
+        __syncthreads();
+    }
+
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int row = i0 + wm * 64 + a * 16 + li;
+        if (row >= M) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = j0 + wn * 64 + b * 16 + g * 4;
+            if (col + 3 < N) epilogue_store<EPI>(e, row, col, acc[a][b]);
+        }
+    }
+}
+
+template <bool XK, bool YK>
+int launch_layout(const vp_gemm_args* a, hipStream_t st) {
+    Operand X{(const bf16*)a->x, a->ldx, a->M}, Y{(const bf16*)a->y, a->ldy, a->N};
+    Epi e{a->epilogue, a->out, a->ldo, a->out2, a->bias, a->resid, a->rowscale, a->rows_per_scale,
+          a->aux, a->ldaux, a->pos, a->pos_rows, a->colscale,
+          a->out_row_div, a->out_row_hi, a->out_row_lo, a->out_row_off};
+    const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int nk = a->K / BK;
+    int split = a->split_k > 0 ? a->split_k : 1;
+    if (split > nk) split = nk;
+    if (a->epilogue != VP_EPI_ATOMIC_F32) split = 1;
+    const int ksplit_tiles = (nk + split - 1) / split;
+    dim3 grid(ntiles, split);
+#define VP_GEMM_CASE(EPI)                                                                         \
+    case EPI:                                                                                     \
+        hipLaunchKernelGGL((gemm_kernel<XK, YK, EPI>), grid, dim3(NTHREADS), 0, st, X, Y, a->M,   \
+                           a->N, a->K, tiles_n, ntiles, ksplit_tiles, e);                         \
+        break;
+    switch (a->epilogue) {
+        VP_GEMM_CASE(VP_EPI_BF16)
+        VP_GEMM_CASE(VP_EPI_GELU)
+        VP_GEMM_CASE(VP_EPI_RESID_F32)
+        VP_GEMM_CASE(VP_EPI_DGELU)
+        VP_GEMM_CASE(VP_EPI_ATOMIC_F32)
+        VP_GEMM_CASE(VP_EPI_F32)
+        VP_GEMM_CASE(VP_EPI_SCALE_RELU)
+        VP_GEMM_CASE(VP_EPI_DRELU)
+        default:
+            return VP_ERR_ARG;
+    }
+#undef VP_GEMM_CASE
+    VP_LAUNCH_RET();
+}
+
+}  // namespace
+
+extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
+    VP_CHECK_ARG(a && a->x && a->y && a->out);
+    VP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
+    VP_CHECK_ARG(a->K % BK == 0);          // reduction extent: whole 64-wide steps
+    VP_CHECK_ARG(a->N % 4 == 0);           // epilogue handles 4 columns per lane
+    VP_CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && a->ldo % 4 == 0);
+    VP_CHECK_ARG(((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->y & 15) == 0 && ((uintptr_t)a->out & 15) == 0);
+    if (a->x_kmajor) VP_CHECK_ARG(a->M % 8 == 0 && a->M >= 8);
+    if (a->y_kmajor) VP_CHECK_ARG(a->N % 8 == 0 && a->N >= 8);
+    if (a->epilogue == VP_EPI_DGELU || a->epilogue == VP_EPI_DRELU) VP_CHECK_ARG(a->aux && a->ldaux % 4 == 0);
+    if (a->rowscale) VP_CHECK_ARG(a->rows_per_scale > 0);
+    if (a->pos) VP_CHECK_ARG(a->pos_rows > 0);
+    if (a->x_kmajor) return a->y_kmajor ? launch_layout<true, true>(a, stream) : launch_layout<true, false>(a, stream);
+    return a->y_kmajor ? launch_layout<false, true>(a, stream) : launch_layout<false, false>(a, stream);
+}

@@ -1,0 +1,383 @@
+// BatchNorm (channels-last), heatmap MSE loss, arg-max for PCK, gradient norm and the
+// fused AdamW step.  All HBM-bound streaming/reduction kernels.
+#include "common.h"
+#include "vitpose_hip.h"
+
+namespace {
+
+inline int grid_for(size_t work_items, int cap = 4096) {
+    size_t g = (work_items + 255) / 256;
+    return (int)(g > (size_t)cap ? cap : (g ? g : 1));
+}
+
+// ---------------- BatchNorm over rows of a channels-last bf16 [M][C] matrix ----------------
+// per-channel sum and sum of squares (f32 atomics into sums[0:C] and sums[C:2C])
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ z, float* __restrict__ sums, int M,
+                                                       int C, int rows_per_block) {
+    __shared__ float red[2][8][256 + 8];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + cx) * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < C) {
+        const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        for (int r = r0 + ry; r < r1; r += 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(z + (size_t)r * C + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)v[j];
+                s[j] += f;
+                q[j] += f * f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[0][ry][cx * 8 + j] = s[j];
+        red[1][ry][cx * 8 + j] = q[j];
+    }
+    __syncthreads();
+    const int c = threadIdx.x, gc = blockIdx.x * 256 + c;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        a += red[0][r][c];
+        b += red[1][r][c];
+    }
+    if (gc < C) {
+        atomicAdd(sums + gc, a);
+        atomicAdd(sums + C + gc, b);
+    }
+}
+
+// training: batch mean / biased var -> scale, shift, saved mean / invstd; running stats updated
+// with momentum and the unbiased variance (torch.nn.BatchNorm2d).  eval (sums == NULL): scale /
+// shift from the running statistics.
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int M, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (sums) {
+        mean = sums[c] / (float)M;
+        var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+        }
+    } else {
+        mean = running_mean[c];
+        var = running_var[c];
+    }
+    const float inv = rsqrtf(var + eps);
+    const float sc = gamma[c] * inv;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) save_mean[c] = mean;
+    if (save_invstd) save_invstd[c] = inv;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const bf16* __restrict__ z, bf16* __restrict__ a,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, size_t n8, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 8) % C);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(z + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf((float)v[j] * scale[c + j] + shift[c + j], 0.f);
+        *reinterpret_cast<bf16x8*>(a + i * 8) = o;
+    }
+}
+
+// backward reduce: g = grad wrt the BN output (ReLU mask already applied);
+// dbeta[c] += sum g, dgamma[c] += sum g * xhat, xhat = (z - mean) * invstd
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ g, const bf16* __restrict__ z,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int M, int C, int rows_per_block) {
+    __shared__ float red[2][8][256 + 8];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + cx) * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < C) {
+        float mu[8], is[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = mean[col + j];
+            is[j] = invstd[col + j];
+        }
+        const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        for (int r = r0 + ry; r < r1; r += 8) {
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + (size_t)r * C + col);
+            const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + (size_t)r * C + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)gv[j];
+                s[j] += f;
+                q[j] += f * ((float)zv[j] - mu[j]) * is[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[0][ry][cx * 8 + j] = s[j];
+        red[1][ry][cx * 8 + j] = q[j];
+    }
+    __syncthreads();
+    const int c = threadIdx.x, gc = blockIdx.x * 256 + c;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        a += red[0][r][c];
+        b += red[1][r][c];
+    }
+    if (gc < C) {
+        atomicAdd(dbeta + gc, a);
+        atomicAdd(dgamma + gc, b);
+    }
+}
+
+// dz = gamma * invstd * (g - dbeta/M - xhat * dgamma/M)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ g, const bf16* __restrict__ z,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, bf16* __restrict__ dz,
+                                                           size_t n8, int C, float invM) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 8) % C);
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + i * 8);
+        const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float is = invstd[c + j];
+            const float xh = ((float)zv[j] - mean[c + j]) * is;
+            o[j] = (bf16)(gamma[c + j] * is * ((float)gv[j] - dbeta[c + j] * invM - xh * dgamma[c + j] * invM));
+        }
+        *reinterpret_cast<bf16x8*>(dz + i * 8) = o;
+    }
+}
+
+// ---------------- heatmap loss (JointsMSELoss) ----------------
+// One thread per (image, heat-map pixel).  Reads the K predictions of its pixel from the
+// channels-last GEMM output [B*HW][ldh] f32, optionally writes them as NCHW f32, and, when a
+// target is given, accumulates  sum_k (w_bk (p - t))^2 * coef  into *loss and writes
+// dL/dp = 2 w_bk^2 (p - t) coef as channels-last bf16 [B*HW][ldh] (pad columns zeroed).
+__global__ __launch_bounds__(256) void heatmap_loss_kernel(const float* __restrict__ heat, int ldh,
+                                                           float* __restrict__ heat_nchw,
+                                                           const float* __restrict__ target,
+                                                           const float* __restrict__ tw, float* __restrict__ loss,
+                                                           bf16* __restrict__ dheat, int B, int K, int HW,
+                                                           float coef) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float part = 0.f;
+    if (i < (size_t)B * HW) {
+        const int b = (int)(i / HW), hw = (int)(i % HW);
+        const float* hp = heat + i * ldh;
+        bf16* dp = dheat ? dheat + i * ldh : nullptr;
+        for (int k = 0; k < K; ++k) {
+            const float p = hp[k];
+            const size_t o = ((size_t)b * K + k) * HW + hw;
+            if (heat_nchw) heat_nchw[o] = p;
+            if (target) {
+                const float w = tw ? tw[b * K + k] : 1.f;
+                const float d = w * (p - target[o]);
+                part += d * d;
+                if (dp) dp[k] = (bf16)(2.f * w * d * coef);
+            }
+        }
+        if (dp)
+            for (int k = K; k < ldh; ++k) dp[k] = (bf16)0.f;
+    }
+    if (target && loss) {
+        part = wave_sum(part);
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * coef);
+    }
+}
+
+// ---------------- per-row arg-max (first maximum, like numpy.argmax) ----------------
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int L, int* __restrict__ idx,
+                                                          float* __restrict__ val) {
+    const float* row = x + (size_t)blockIdx.x * L;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const float v = row[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = sv[threadIdx.x + s];
+            const int j = si[threadIdx.x + s];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) {
+                sv[threadIdx.x] = v;
+                si[threadIdx.x] = j;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        idx[blockIdx.x] = si[0];
+        if (val) val[blockIdx.x] = sv[0];
+    }
+}
+
+// ---------------- gradient norm + AdamW over flat buffers ----------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ out) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// One block per chunk of one parameter tensor; chunk table rows = {start, length} (elements,
+// multiples of 4), with a per-chunk lr scale and weight decay.  torch.optim.AdamW update order.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16* __restrict__ p_bf16, const long* __restrict__ chunk_start,
+                                                    const int* __restrict__ chunk_len,
+                                                    const float* __restrict__ chunk_lr_scale,
+                                                    const float* __restrict__ chunk_wd, float lr, float beta1,
+                                                    float beta2, float eps, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ gnorm_sq, float max_norm,
+                                                    float grad_scale) {
+    const long s0 = chunk_start[blockIdx.x];
+    const int len = chunk_len[blockIdx.x];
+    const float lr_c = lr * chunk_lr_scale[blockIdx.x], wd = chunk_wd[blockIdx.x];
+    float clip = grad_scale;
+    if (gnorm_sq && max_norm > 0.f) {
+        const float tn = sqrtf(*gnorm_sq) * grad_scale;
+        clip *= fminf(1.f, max_norm / (tn + 1e-6f));
+    }
+    const float step = lr_c / bc1;
+    for (int i = threadIdx.x * 4; i < len; i += 256 * 4) {
+        const long o = s0 + i;
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + o);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o) * clip;
+        f32x4 mv = *reinterpret_cast<f32x4*>(m + o);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pv[r] *= 1.f - lr_c * wd;
+            mv[r] += (1.f - beta1) * (gv[r] - mv[r]);
+            vv[r] = beta2 * vv[r] + (1.f - beta2) * gv[r] * gv[r];
+            pv[r] -= step * mv[r] / (sqrtf(vv[r]) / bc2_sqrt + eps);
+        }
+        *reinterpret_cast<f32x4*>(p + o) = pv;
+        *reinterpret_cast<f32x4*>(m + o) = mv;
+        *reinterpret_cast<f32x4*>(v + o) = vv;
+        if (p_bf16) *reinterpret_cast<bf16x4*>(p_bf16 + o) = pack4(pv[0], pv[1], pv[2], pv[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        *reinterpret_cast<bf16x4*>(y + i * 4) = pack4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int vp_bn_stats(const void* z, float* sums, int M, int C, hipStream_t stream) {
+    VP_CHECK_ARG(z && sums && M > 0 && C > 0 && C % 8 == 0);
+    const int gx = (C + 255) / 256;
+    int gy = (M + 255) / 256;
+    if (gy > 512) gy = 512;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)z, sums, M, C, (M + gy - 1) / gy);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_bn_finalize(const float* sums, int M, int C, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                              float* shift, float* save_mean, float* save_invstd, hipStream_t stream) {
+    VP_CHECK_ARG(C > 0 && gamma && beta && scale && shift && (sums || (running_mean && running_var)));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, M, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_bn_apply_relu(const void* z, void* a, const float* scale, const float* shift, int M, int C,
+                                hipStream_t stream) {
+    VP_CHECK_ARG(z && a && scale && shift && M > 0 && C % 8 == 0);
+    const size_t n8 = (size_t)M * C / 8;
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid_for(n8)), dim3(256), 0, stream, (const bf16*)z, (bf16*)a, scale,
+                       shift, n8, C);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_bn_bwd(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+                         float* dgamma, float* dbeta, void* dz, int M, int C, hipStream_t stream) {
+    VP_CHECK_ARG(g && z && mean && invstd && gamma && dgamma && dbeta && dz && M > 0 && C % 8 == 0);
+    const int gx = (C + 255) / 256;
+    int gy = (M + 255) / 256;
+    if (gy > 512) gy = 512;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)g, (const bf16*)z, mean,
+                       invstd, dgamma, dbeta, M, C, (M + gy - 1) / gy);
+    const size_t n8 = (size_t)M * C / 8;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n8)), dim3(256), 0, stream, (const bf16*)g, (const bf16*)z,
+                       mean, invstd, gamma, dgamma, dbeta, (bf16*)dz, n8, C, 1.f / (float)M);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, const float* target, const float* tw,
+                               float* loss, void* dheat, int B, int K, int HW, float loss_weight, hipStream_t stream) {
+    VP_CHECK_ARG(heat && B > 0 && K > 0 && K <= ldh && HW > 0);
+    VP_CHECK_ARG(heat_nchw || target);
+    const float coef = loss_weight / ((float)B * (float)K * (float)HW);
+    const size_t n = (size_t)B * HW;
+    hipLaunchKernelGGL(heatmap_loss_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heat, ldh,
+                       heat_nchw, target, tw, loss, (bf16*)dheat, B, K, HW, coef);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_argmax_rows(const float* x, int rows, int L, int* idx, float* val, hipStream_t stream) {
+    VP_CHECK_ARG(x && idx && rows > 0 && L > 0);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, L, idx, val);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_sumsq_f32(const float* x, size_t n, float* out, hipStream_t stream) {
+    VP_CHECK_ARG(x && out && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4, 1024)), dim3(256), 0, stream, x, n / 4, out);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const long* chunk_start,
+                             const int* chunk_len, const float* chunk_lr_scale, const float* chunk_wd, int nchunks,
+                             float lr, float beta1, float beta2, float eps, int step, const float* gnorm_sq,
+                             float max_norm, float grad_scale, hipStream_t stream) {
+    VP_CHECK_ARG(p && g && m && v && chunk_start && chunk_len && chunk_lr_scale && chunk_wd && nchunks > 0 && step > 0);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, p, g, m, v, (bf16*)p_bf16, chunk_start,
+                       chunk_len, chunk_lr_scale, chunk_wd, lr, beta1, beta2, eps, bc1, bc2s, gnorm_sq, max_norm,
+                       grad_scale);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
+    VP_CHECK_ARG(x && y && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, x, (bf16*)y, n / 4);
+    VP_LAUNCH_RET();
+}

@@ -1,0 +1,328 @@
+"""Host-side sequencing of the HIP kernels: parameter storage, workspaces and the
+recorded launch plans of the ViT backbone and the top-down heatmap head.
+
+Data layout in HBM (one process per GPU):
+  * parameters: one flat f32 buffer (master weights, 256-byte aligned tensors), a flat
+    bf16 mirror (MFMA operands) and a flat f32 gradient buffer with the same offsets;
+  * activations: token-major / channels-last (`[B*tokens][C]`): the f32 residual stream
+    and bf16 GEMM operands; the 16x12 token grid IS the NHWC feature map of the head;
+  * everything a backward pass needs is kept per block (HBM is 288 GB, the whole
+    ViTPose-B activation set at 64 images is ~4 GB), nothing is recomputed except
+    the attention probabilities.
+"""
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .plan import Plan
+
+ALIGN = 64  # elements; keeps every tensor 256-byte aligned in the f32 buffers
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class ParamStore:
+    """Flat master / bf16 / gradient buffers with named views."""
+
+    def __init__(self, named_shapes: Sequence[Tuple[str, Tuple[int, ...]]], device):
+        self.device = torch.device(device)
+        self.shapes = dict(named_shapes)
+        self.names = [n for n, _ in named_shapes]
+        self.offsets = {}
+        off = 0
+        for n, s in named_shapes:
+            self.offsets[n] = off
+            off += _round_up(int(math.prod(s)), ALIGN)
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.half = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+
+    def _v(self, buf, name):
+        o = self.offsets[name]
+        s = self.shapes[name]
+        return buf[o:o + int(math.prod(s))].view(s)
+
+    def view(self, name):
+        return self._v(self.data, name)
+
+    def gview(self, name):
+        return self._v(self.grad, name)
+
+    def hview(self, name):
+        return self._v(self.half, name)
+
+    def load(self, sd: Dict[str, torch.Tensor], strict=True):
+        for n in self.names:
+            if n in sd:
+                self.view(n).copy_(sd[n].to(self.device, torch.float32))
+            elif strict:
+                raise KeyError(n)
+
+    def state_dict(self):
+        return {n: self.view(n).clone() for n in self.names}
+
+
+class Workspace:
+    """Named device buffers (allocated once per shape, owned by torch)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs = {}
+
+    def get(self, name, shape, dtype, zero=False):
+        key = name
+        t = self.bufs.get(key)
+        shape = tuple(int(s) for s in shape)
+        if t is None or t.shape != shape or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def bf16(self, name, *shape, zero=False):
+        return self.get(name, shape, torch.bfloat16, zero)
+
+    def f32(self, name, *shape, zero=False):
+        return self.get(name, shape, torch.float32, zero)
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+def _split_k(M, N, K, target_blocks=768):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nk = K // 64
+    return max(1, min(nk, (target_blocks + tiles - 1) // tiles))
+
+
+# =====================================================================================
+# ViT backbone
+# =====================================================================================
+def vit_param_shapes(cfg) -> List[Tuple[str, Tuple[int, ...]]]:
+    """State-dict keys/shapes of the backbone (identical to the reference ViT's)."""
+    E = cfg['embed_dim']
+    Hd = int(E * cfg.get('mlp_ratio', 4))
+    p = cfg['patch_size']
+    H, W = cfg['img_size']
+    ratio = cfg.get('ratio', 1)
+    npos = (H // p) * (W // p) * ratio ** 2 + 1
+    out = [('pos_embed', (1, npos, E)),
+           ('patch_embed.proj.weight', (E, cfg.get('in_chans', 3), p, p)),
+           ('patch_embed.proj.bias', (E,))]
+    for i in range(cfg['depth']):
+        b = f'blocks.{i}.'
+        out += [(b + 'norm1.weight', (E,)), (b + 'norm1.bias', (E,)),
+                (b + 'attn.qkv.weight', (3 * E, E))]
+        if cfg.get('qkv_bias', True):
+            out += [(b + 'attn.qkv.bias', (3 * E,))]
+        out += [(b + 'attn.proj.weight', (E, E)), (b + 'attn.proj.bias', (E,)),
+                (b + 'norm2.weight', (E,)), (b + 'norm2.bias', (E,)),
+                (b + 'mlp.fc1.weight', (Hd, E)), (b + 'mlp.fc1.bias', (Hd,)),
+                (b + 'mlp.fc2.weight', (E, Hd)), (b + 'mlp.fc2.bias', (E,))]
+    if cfg.get('last_norm', True):
+        out += [('last_norm.weight', (E,)), ('last_norm.bias', (E,))]
+    return out
+
+
+class VitRunner:
+    """Records forward / backward plans of the ViT backbone over a ParamStore."""
+
+    def __init__(self, cfg: dict, store: ParamStore, prefix: str = ''):
+        self.cfg, self.store, self.pre = cfg, store, prefix
+        self.E = cfg['embed_dim']
+        self.depth = cfg['depth']
+        self.heads = cfg['num_heads']
+        self.d = self.E // self.heads
+        self.hidden = int(self.E * cfg.get('mlp_ratio', 4))
+        self.patch = cfg['patch_size']
+        ratio = cfg.get('ratio', 1)
+        self.stride = self.patch // ratio
+        self.pad = 4 + 2 * (ratio // 2 - 1)
+        H, W = cfg['img_size']
+        self.img_hw = (H, W)
+        self.C = cfg.get('in_chans', 3)
+        self.Hp = (H + 2 * self.pad - self.patch) // self.stride + 1
+        self.Wp = (W + 2 * self.pad - self.patch) // self.stride + 1
+        self.T = self.Hp * self.Wp
+        self.scale = cfg.get('qk_scale') or self.d ** -0.5
+        self.Kpe = self.C * self.patch * self.patch
+        if self.T + 1 != store.shapes[prefix + 'pos_embed'][1]:
+            raise ValueError('pos_embed length does not match the patch grid')
+        if self.T != 192 or self.d not in (32, 64):
+            raise NotImplementedError(
+                f'attention kernel covers 192 tokens and head_dim 32/64 (got {self.T}, {self.d})')
+        if self.E % 64 or self.hidden % 64 or self.Kpe % 64:
+            raise NotImplementedError('channel counts must be multiples of 64')
+        dev = store.device
+        self.pos_comb = torch.empty(self.T, self.E, dtype=torch.float32, device=dev)
+        self.dpos = torch.empty(self.T, self.E, dtype=torch.float32, device=dev)
+        rates = torch.linspace(0, cfg.get('drop_path_rate', 0.), self.depth)
+        self.dp_rates = [r.item() for r in rates]
+
+    # -- names --
+    def w(self, n):
+        return self.store.view(self.pre + n)
+
+    def h(self, n):
+        return self.store.hview(self.pre + n)
+
+    def g(self, n):
+        return self.store.gview(self.pre + n)
+
+    def has(self, n):
+        return (self.pre + n) in self.store.shapes
+
+    def refresh_derived(self):
+        """Weight-derived constants (after every weight update)."""
+        pe = self.w('pos_embed')[0]
+        torch.add(pe[1:], pe[:1], out=self.pos_comb)
+
+    def sample_drop_path(self, dp: torch.Tensor, generator=None):
+        """Fill dp [depth][2][B] with per-sample DropPath scales floor(keep + U) / keep."""
+        u = torch.rand(dp.shape, device=dp.device, generator=generator)
+        keep = 1.0 - torch.tensor(self.dp_rates, device=dp.device).view(-1, 1, 1)
+        torch.div(torch.floor(keep + u), keep, out=dp)
+
+    # -- forward --
+    def record_forward(self, plan: Plan, ws: Workspace, img: torch.Tensor, B: int, training: bool,
+                       dp: Optional[torch.Tensor] = None, tokens_f32: Optional[torch.Tensor] = None):
+        """img [B,C,H,W] f32 -> returns the final token-major bf16 feature [B*T][E]."""
+        E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
+        H, W = self.img_hw
+        col = ws.bf16('pe_col', M, self.Kpe)
+        plan.patch_im2col(img, col, B, self.C, H, W, self.patch, self.stride, self.pad)
+        # training keeps every block's tensors (suffix .i); inference reuses one set and
+        # ping-pongs the residual stream between two buffers
+        sfx = (lambda i: f'.{i}') if training else (lambda i: '')
+        x = ws.f32('x_in.0' if training else 'x_a', M, E)
+        plan.gemm(col, self.h('patch_embed.proj.weight'), x, M, E, self.Kpe, ldx=self.Kpe, ldy=self.Kpe, ldo=E,
+                  epilogue=_lib.VP_EPI_RESID_F32, bias=self.w('patch_embed.proj.bias'), pos=self.pos_comb,
+                  pos_rows=T)
+        for i in range(self.depth):
+            b = f'blocks.{i}.'
+            s = sfx(i)
+            xn = ws.bf16('xn1' + s, M, E)
+            mean1, rstd1 = ws.f32('mean1' + s, M), ws.f32('rstd1' + s, M)
+            plan.layernorm_fwd(x, self.w(b + 'norm1.weight'), self.w(b + 'norm1.bias'), xn, None,
+                               mean1 if training else None, rstd1 if training else None, M, E)
+            qkv = ws.bf16('qkv' + s, M, 3 * E)
+            plan.gemm(xn, self.h(b + 'attn.qkv.weight'), qkv, M, 3 * E, E, ldx=E, ldy=E, ldo=3 * E,
+                      bias=self.w(b + 'attn.qkv.bias') if self.has(b + 'attn.qkv.bias') else None)
+            ao = ws.bf16('ao' + s, M, E)
+            lse = ws.f32('lse' + s, B * self.heads, T)
+            plan.attention_fwd(qkv, ao, lse if training else None, B, self.heads, self.d, T, self.scale)
+            xm = ws.f32('x_mid' + s if training else 'x_b', M, E)
+            use_dp = training and dp is not None and self.dp_rates[i] > 0
+            plan.gemm(ao, self.h(b + 'attn.proj.weight'), xm, M, E, E, ldx=E, ldy=E, ldo=E,
+                      epilogue=_lib.VP_EPI_RESID_F32, bias=self.w(b + 'attn.proj.bias'), resid=x,
+                      rowscale=dp[i, 0] if use_dp else None, rows_per_scale=T)
+            xn2 = ws.bf16('xn2' + s, M, E)
+            mean2, rstd2 = ws.f32('mean2' + s, M), ws.f32('rstd2' + s, M)
+            plan.layernorm_fwd(xm, self.w(b + 'norm2.weight'), self.w(b + 'norm2.bias'), xn2, None,
+                               mean2 if training else None, rstd2 if training else None, M, E)
+            hact = ws.bf16('h' + s, M, Hd)
+            u = ws.bf16('u' + s, M, Hd) if training else None
+            plan.gemm(xn2, self.h(b + 'mlp.fc1.weight'), hact, M, Hd, E, ldx=E, ldy=E, ldo=Hd,
+                      epilogue=_lib.VP_EPI_GELU, out2=u, bias=self.w(b + 'mlp.fc1.bias'))
+            xo = ws.f32(f'x_in.{i + 1}' if training else 'x_a', M, E)
+            plan.gemm(hact, self.h(b + 'mlp.fc2.weight'), xo, M, E, Hd, ldx=Hd, ldy=Hd, ldo=E,
+                      epilogue=_lib.VP_EPI_RESID_F32, bias=self.w(b + 'mlp.fc2.bias'), resid=xm,
+                      rowscale=dp[i, 1] if use_dp else None, rows_per_scale=T)
+            x = xo
+        feat = ws.bf16('feat', M, E)
+        if self.cfg.get('last_norm', True):
+            mean, rstd = ws.f32('mean_l', M), ws.f32('rstd_l', M)
+            plan.layernorm_fwd(x, self.w('last_norm.weight'), self.w('last_norm.bias'), feat, tokens_f32,
+                               mean if training else None, rstd if training else None, M, E)
+        else:
+            plan.cast_f32_bf16(x, feat, M * E)
+            if tokens_f32 is not None:
+                plan.strided_cast(x, tokens_f32, (1, 1, 1, M * E), (0, 0, 0, 1))
+        self._x_last = x
+        return feat
+
+    # -- backward (training workspaces of record_forward(training=True) required) --
+    def record_backward(self, plan: Plan, ws: Workspace, dfeat: torch.Tensor, B: int,
+                        dp: Optional[torch.Tensor] = None):
+        """dfeat = bf16 [B*T][E] gradient wrt the final feature.  Accumulates into store.grad."""
+        E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
+        ATOM = _lib.VP_EPI_ATOMIC_F32
+
+        def dp_scale(i, j):
+            if dp is not None and i >= 0 and self.dp_rates[i] > 0:
+                return dp[i, j]
+            return None
+
+        dx_a, dx_b = ws.f32('dx_a', M, E), ws.f32('dx_b', M, E)
+        dxb = ws.bf16('dxb', M, E)
+        du = ws.bf16('du', M, Hd)
+        dxn = ws.bf16('dxn', M, E)
+        dao = ws.bf16('dao', M, E)
+        dqkv = ws.bf16('dqkv', M, 3 * E)
+        last = self.depth - 1
+        x_last = ws.bufs[f'x_in.{self.depth}']
+        if self.cfg.get('last_norm', True):
+            plan.layernorm_bwd(dfeat, x_last, ws.bufs['mean_l'], ws.bufs['rstd_l'], self.w('last_norm.weight'),
+                               None, dx_a, dxb, dp_scale(last, 1), T, self.g('last_norm.weight'),
+                               self.g('last_norm.bias'), self.g(f'blocks.{last}.mlp.fc2.bias'), M, E)
+        else:
+            raise NotImplementedError('last_norm=False backward')
+        dx = dx_a
+        other = dx_b
+        for i in range(self.depth - 1, -1, -1):
+            b = f'blocks.{i}.'
+            s = f'.{i}'
+            g = ws.bufs
+            # ---- MLP branch: x_out = x_mid + s * (fc2(gelu(fc1(LN2(x_mid)))))
+            # du = (dxb W2) * gelu'(u)
+            plan.gemm(dxb, self.h(b + 'mlp.fc2.weight'), du, M, Hd, E, ldx=E, ldy=Hd, ldo=Hd, y_kmajor=True,
+                      epilogue=_lib.VP_EPI_DGELU, aux=g['u' + s], ldaux=Hd)
+            # dW2 [E][Hd] += dxb^T h
+            plan.gemm(dxb, g['h' + s], self.g(b + 'mlp.fc2.weight'), E, Hd, M, ldx=E, ldy=Hd, ldo=Hd,
+                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(E, Hd, M))
+            # dxn2 = du W1 ; dW1 [Hd][E] += du^T xn2 ; db1 = colsum(du)
+            plan.gemm(du, self.h(b + 'mlp.fc1.weight'), dxn, M, E, Hd, ldx=Hd, ldy=E, ldo=E, y_kmajor=True)
+            plan.gemm(du, g['xn2' + s], self.g(b + 'mlp.fc1.weight'), Hd, E, M, ldx=Hd, ldy=E, ldo=E,
+                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(Hd, E, M))
+            plan.colsum(du, self.g(b + 'mlp.fc1.bias'), M, Hd, Hd)
+            # LN2 backward, residual add, scaled bf16 copy for the attention branch, proj bias grad
+            plan.layernorm_bwd(dxn, g['x_mid' + s], g['mean2' + s], g['rstd2' + s], self.w(b + 'norm2.weight'),
+                               dx, other, dxb, dp_scale(i, 0), T, self.g(b + 'norm2.weight'),
+                               self.g(b + 'norm2.bias'), self.g(b + 'attn.proj.bias'), M, E)
+            dx, other = other, dx
+            # ---- attention branch
+            plan.gemm(dxb, self.h(b + 'attn.proj.weight'), dao, M, E, E, ldx=E, ldy=E, ldo=E, y_kmajor=True)
+            plan.gemm(dxb, g['ao' + s], self.g(b + 'attn.proj.weight'), E, E, M, ldx=E, ldy=E, ldo=E,
+                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(E, E, M))
+            plan.attention_bwd(g['qkv' + s], g['ao' + s], dao, g['lse' + s], dqkv, B, self.heads, self.d, T,
+                               self.scale)
+            plan.gemm(dqkv, self.h(b + 'attn.qkv.weight'), dxn, M, E, 3 * E, ldx=3 * E, ldy=E, ldo=E, y_kmajor=True)
+            plan.gemm(dqkv, g['xn1' + s], self.g(b + 'attn.qkv.weight'), 3 * E, E, M, ldx=3 * E, ldy=E, ldo=E,
+                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(3 * E, E, M))
+            if self.has(b + 'attn.qkv.bias'):
+                plan.colsum(dqkv, self.g(b + 'attn.qkv.bias'), M, 3 * E, 3 * E)
+            # LN1 backward: bf16 copy is scaled for the previous block's MLP branch (or unscaled for
+            # the patch embedding), its column sum is that branch's fc2 bias (or the patch bias) grad
+            nxt_bias = self.g(f'blocks.{i - 1}.mlp.fc2.bias') if i > 0 else self.g('patch_embed.proj.bias')
+            plan.layernorm_bwd(dxn, g['x_in' + s], g['mean1' + s], g['rstd1' + s], self.w(b + 'norm1.weight'),
+                               dx, other, dxb, dp_scale(i - 1, 1), T, self.g(b + 'norm1.weight'),
+                               self.g(b + 'norm1.bias'), nxt_bias, M, E)
+            dx, other = other, dx
+        # ---- patch embedding + position embedding
+        plan.gemm(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
+                  ldo=self.Kpe, x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(E, self.Kpe, M))
+        plan.batch_sum(dx, self.dpos, B, T * E)
+        gp = self.g('pos_embed')[0]
+
+        def pos_grad():
+            # pos_embed grad: rows 1.. per token, row 0 broadcast over tokens ([T][E] adds: plumbing)
+            gp[1:] += self.dpos
+            gp[0] += self.dpos.sum(0)
+        plan.host(pos_grad)
+        self._dx0 = dx

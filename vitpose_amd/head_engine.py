@@ -1,0 +1,209 @@
+"""Launch plans of the top-down heatmap head on channels-last activations.
+
+Classic decoder: each ConvTranspose2d(k=4, s=2, p=1, bias=False) is four sub-pixel
+GEMMs (one per output parity), BatchNorm is a column reduction + folded scale/shift,
+the final 1x1 conv a skinny GEMM (17 output channels padded to 64 columns).
+"""
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .engine import ParamStore, Workspace, _split_k
+from .plan import Plan
+
+KPAD = 64  # the K=17 heat-map channels are padded to one 64-wide MFMA K step / 4 column tiles
+
+
+def head_param_shapes(cfg) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[Tuple[str, Tuple[int, ...]]]]:
+    """(parameters, buffers) with the reference head's state-dict keys/shapes."""
+    params, bufs = [], []
+    cin = cfg['in_channels']
+    for li in range(cfg.get('num_deconv_layers', 0)):
+        k = cfg['num_deconv_kernels'][li]
+        co = cfg['num_deconv_filters'][li]
+        params.append((f'deconv_layers.{3 * li}.weight', (cin, co, k, k)))
+        bn = f'deconv_layers.{3 * li + 1}.'
+        params += [(bn + 'weight', (co,)), (bn + 'bias', (co,))]
+        bufs += [(bn + 'running_mean', (co,)), (bn + 'running_var', (co,))]
+        cin = co
+    fk = (cfg.get('extra') or {}).get('final_conv_kernel', 1)
+    if fk:
+        params += [('final_layer.weight', (cfg['out_channels'], cin, fk, fk)),
+                   ('final_layer.bias', (cfg['out_channels'],))]
+    return params, bufs
+
+
+class HeadRunner:
+    def __init__(self, cfg: dict, store: ParamStore, buffers: dict, grid_hw: Tuple[int, int], prefix: str = ''):
+        """`buffers`: name -> f32 device tensor for the BN running statistics."""
+        self.cfg, self.store, self.pre, self.buffers = cfg, store, prefix, buffers
+        self.nl = cfg.get('num_deconv_layers', 0)
+        self.K = cfg['out_channels']
+        self.Hg, self.Wg = grid_hw
+        self.cin = cfg['in_channels']
+        extra = cfg.get('extra') or {}
+        self.fk = extra.get('final_conv_kernel', 1)
+        self.upsample = cfg.get('upsample', 0)
+        if extra.get('num_conv_layers', 0):
+            raise NotImplementedError('extra conv layers in the head')
+        if self.nl:
+            if any(k != 4 for k in cfg['num_deconv_kernels'][:self.nl]):
+                raise NotImplementedError('HIP head covers deconv kernel size 4 (the ViTPose configs)')
+            if self.fk != 1 or self.upsample:
+                raise NotImplementedError('deconv head with final_conv_kernel != 1 or upsample')
+        if self.K > KPAD:
+            raise NotImplementedError('more than 64 keypoints')
+        dev = store.device
+        self.chans = [self.cin] + [cfg['num_deconv_filters'][i] for i in range(self.nl)]
+        # compute-layout weight copies (bf16): sub-pixel phase matrices and the 16-tap matrix
+        self.wph = [torch.empty(4, self.chans[l + 1], 4 * self.chans[l], dtype=torch.bfloat16, device=dev)
+                    for l in range(self.nl)]
+        self.wd = [torch.empty(self.chans[l], 16 * self.chans[l + 1], dtype=torch.bfloat16, device=dev)
+                   for l in range(self.nl)]
+        self.dwd = [torch.zeros(self.chans[l], 16 * self.chans[l + 1], dtype=torch.float32, device=dev)
+                    for l in range(self.nl)]
+        cl = self.chans[-1]
+        self.wf = torch.zeros(KPAD, cl, dtype=torch.bfloat16, device=dev)
+        self.bf = torch.zeros(KPAD, dtype=torch.float32, device=dev)
+        self.dwf = torch.zeros(KPAD, cl, dtype=torch.float32, device=dev)
+        self.dbf = torch.zeros(KPAD, dtype=torch.float32, device=dev)
+        self.bn_scale = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
+        self.bn_shift = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
+        self.bn_mean = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
+        self.bn_invstd = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
+        self.bn_sums = [torch.zeros(2 * c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
+
+    def w(self, n):
+        return self.store.view(self.pre + n)
+
+    def g(self, n):
+        return self.store.gview(self.pre + n)
+
+    def buf(self, n):
+        return self.buffers[self.pre + n]
+
+    # -- weight re-layout (recorded once, replayed after every weight update) --
+    def record_weight_prep(self, plan: Plan):
+        for l in range(self.nl):
+            W = self.w(f'deconv_layers.{3 * l}.weight')  # [Cin][Cout][4][4] f32
+            ci, co = self.chans[l], self.chans[l + 1]
+            for py in range(2):
+                for px in range(2):
+                    # wph[phase][co][(ty,tx,ci)] = W[ci][co][(1-py)+2ty][(1-px)+2tx]
+                    src = W.view(-1)[(1 - py) * 4 + (1 - px):]
+                    plan.strided_cast(src, self.wph[l][py * 2 + px], (co, 2, 2, ci), (16, 8, 2, co * 16))
+            # wd[ci][(ky,kx,co)] = W[ci][co][ky][kx]
+            plan.strided_cast(W, self.wd[l], (ci, 16, co, 1), (co * 16, 1, 16, 0))
+        Wf = self.w('final_layer.weight')  # [K][C][1][1]
+        plan.strided_cast(Wf, self.wf, (1, 1, 1, Wf.numel()), (0, 0, 0, 1))
+        bf, b = self.bf, self.w('final_layer.bias')
+        plan.host(lambda: bf[:b.numel()].copy_(b))
+
+    # -- forward --
+    def record_forward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, B: int, training: bool,
+                       heat_nchw: torch.Tensor, target=None, tw=None, loss=None, want_grad=False,
+                       loss_weight: float = 1.0):
+        """feat: bf16 channels-last [B*Hg*Wg][Cin].  Writes heat_nchw [B][K][4Hg*4Wg...] f32."""
+        H, W = self.Hg, self.Wg
+        a = feat
+        sfx = (lambda l: f'.{l}') if training else (lambda l: '')
+        for l in range(self.nl):
+            ci, co = self.chans[l], self.chans[l + 1]
+            Min, Mout = B * H * W, B * 4 * H * W
+            col = ws.bf16('dc_col', Min * 4 * ci)
+            z = ws.bf16('z' + sfx(l) + ('' if training else f'_{l}'), Mout, co)
+            bn = f'deconv_layers.{3 * l + 1}.'
+            if not training:
+                plan.bn_finalize(None, Mout, co, self.w(bn + 'weight'), self.w(bn + 'bias'),
+                                 self.buf(bn + 'running_mean'), self.buf(bn + 'running_var'), 0.1, 1e-5,
+                                 self.bn_scale[l], self.bn_shift[l], None, None)
+            for py in range(2):
+                for px in range(2):
+                    plan.deconv_phase_im2col(a, col, B, H, W, ci, py, px)
+                    plan.gemm(col, self.wph[l][py * 2 + px], z, Min, co, 4 * ci, ldx=4 * ci, ldy=4 * ci, ldo=co,
+                              epilogue=_lib.VP_EPI_BF16 if training else _lib.VP_EPI_SCALE_RELU,
+                              colscale=None if training else self.bn_scale[l],
+                              bias=None if training else self.bn_shift[l],
+                              row_map=(W, 4 * W, 2, py * 2 * W + px))
+            if training:
+                plan.memset0(self.bn_sums[l])
+                plan.bn_stats(z, self.bn_sums[l], Mout, co)
+                plan.bn_finalize(self.bn_sums[l], Mout, co, self.w(bn + 'weight'), self.w(bn + 'bias'),
+                                 self.buf(bn + 'running_mean'), self.buf(bn + 'running_var'), 0.1, 1e-5,
+                                 self.bn_scale[l], self.bn_shift[l], self.bn_mean[l], self.bn_invstd[l])
+                act = ws.bf16(f'a.{l}', Mout, co)
+                plan.bn_apply_relu(z, act, self.bn_scale[l], self.bn_shift[l], Mout, co)
+                a = act
+            else:
+                a = z
+            H, W = 2 * H, 2 * W
+        Mh = B * H * W
+        cl = self.chans[-1]
+        heat = ws.f32('heat_cl', Mh, KPAD)
+        plan.gemm(a, self.wf, heat, Mh, KPAD, cl, ldx=cl, ldy=cl, ldo=KPAD, epilogue=_lib.VP_EPI_F32, bias=self.bf)
+        dheat = ws.bf16('dheat', Mh, KPAD) if want_grad else None
+        if loss is not None:
+            plan.memset0(loss)
+        plan.heatmap_loss(heat, KPAD, heat_nchw, target, tw, loss, dheat, B, self.K, H * W, loss_weight)
+        self._last_act = a
+        self.out_hw = (H, W)
+        return dheat
+
+    # -- backward: returns the bf16 gradient wrt `feat` --
+    def record_backward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat: torch.Tensor, B: int):
+        ATOM = _lib.VP_EPI_ATOMIC_F32
+        H, W = self.out_hw
+        Mh = B * H * W
+        cl = self.chans[-1]
+        a_last = ws.bufs[f'a.{self.nl - 1}'] if self.nl else feat
+        # final 1x1 conv
+        plan.memset0(self.dwf)
+        plan.memset0(self.dbf)
+        plan.gemm(dheat, a_last, self.dwf, KPAD, cl, Mh, ldx=KPAD, ldy=cl, ldo=cl, x_kmajor=True, y_kmajor=True,
+                  epilogue=ATOM, split_k=_split_k(KPAD, cl, Mh, 512))
+        plan.colsum(dheat, self.dbf, Mh, KPAD, KPAD)
+        gW, gb, dwf, dbf, K = self.g('final_layer.weight'), self.g('final_layer.bias'), self.dwf, self.dbf, self.K
+
+        def final_grads():
+            gW.view(K, -1).add_(dwf[:K])
+            gb.add_(dbf[:K])
+        plan.host(final_grads)
+        g = ws.bf16('hg', Mh, cl)
+        if self.nl == 0:
+            plan.gemm(dheat, self.wf, g, Mh, cl, KPAD, ldx=KPAD, ldy=cl, ldo=cl, y_kmajor=True)
+            return g
+        plan.gemm(dheat, self.wf, g, Mh, cl, KPAD, ldx=KPAD, ldy=cl, ldo=cl, y_kmajor=True,
+                  epilogue=_lib.VP_EPI_DRELU, aux=a_last, ldaux=cl)
+        for l in range(self.nl - 1, -1, -1):
+            ci, co = self.chans[l], self.chans[l + 1]
+            Hi, Wi = H // 2, W // 2
+            Mout, Min = B * H * W, B * Hi * Wi
+            bn = f'deconv_layers.{3 * l + 1}.'
+            dz = ws.bf16('hdz', Mout, co)
+            plan.bn_bwd(g, ws.bufs[f'z.{l}'], self.bn_mean[l], self.bn_invstd[l], self.w(bn + 'weight'),
+                        self.g(bn + 'weight'), self.g(bn + 'bias'), dz, Mout, co)
+            G = ws.bf16('hG', Min * 16 * co)
+            plan.deconv_out_gather16(dz, G, B, Hi, Wi, co)
+            a_in = ws.bufs[f'a.{l - 1}'] if l > 0 else feat
+            # dWd [ci][16co] = a_in^T G
+            plan.memset0(self.dwd[l])
+            plan.gemm(a_in, G, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=16 * co, ldo=16 * co, x_kmajor=True,
+                      y_kmajor=True, epilogue=ATOM, split_k=_split_k(ci, 16 * co, Min, 1024))
+            gw, dwd = self.g(f'deconv_layers.{3 * l}.weight'), self.dwd[l]
+
+            def wgrad(gw=gw, dwd=dwd, ci=ci, co=co):
+                # [ci][(ky,kx)][co] -> [ci][co][ky][kx]
+                gw.add_(dwd.view(ci, 16, co).permute(0, 2, 1).reshape(gw.shape))
+            plan.host(wgrad)
+            # data gradient wrt the layer input: G Wd^T  (+ ReLU mask of the previous activation)
+            gin = ws.bf16('hg_in' if l % 2 else 'hg_in2', Min, ci)
+            if l > 0:
+                plan.gemm(G, self.wd[l], gin, Min, ci, 16 * co, ldx=16 * co, ldy=16 * co, ldo=ci,
+                          epilogue=_lib.VP_EPI_DRELU, aux=a_in, ldaux=ci)
+            else:
+                plan.gemm(G, self.wd[l], gin, Min, ci, 16 * co, ldx=16 * co, ldy=16 * co, ldo=ci)
+            g = gin
+            H, W = Hi, Wi
+        return g

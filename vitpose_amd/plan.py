@@ -1,0 +1,170 @@
+"""Launch plans: a model pass is recorded ONCE as a flat list of C-ABI calls with
+pre-bound device pointers, then replayed every step with no Python work per kernel
+beyond the foreign call itself.  Tensors are only used for memory ownership
+(torch allocates, the plan keeps them alive) and for the current HIP stream.
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, 'device tensor expected'
+    return c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: must be contiguous')
+
+
+class Plan:
+    def __init__(self):
+        self.L = _lib.lib()
+        self.calls = []     # (name, cfunc, args)
+        self.keep = []      # tensors / ctypes objects that must outlive the plan
+
+    # -- replay --
+    def run(self, stream=None):
+        s = c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+        for name, fn, args in self.calls:
+            rc = fn(*args, s)
+            if rc != 0:
+                raise KernelError(f'{name} failed with status {rc}')
+
+    def _add(self, name, *args, keep=()):
+        self.calls.append((name, getattr(self.L, name), args))
+        self.keep.extend(keep)
+
+    def __len__(self):
+        return len(self.calls)
+
+    # -- recorded ops --
+    def gemm(self, x, y, out, M, N, K, *, ldx, ldy, ldo, x_kmajor=False, y_kmajor=False,
+             epilogue=_lib.VP_EPI_BF16, out2=None, bias=None, colscale=None, resid=None,
+             rowscale=None, rows_per_scale=0, aux=None, ldaux=0, pos=None, pos_rows=0, split_k=1,
+             row_map=None):
+        a = GemmArgs()
+        a.M, a.N, a.K = M, N, K
+        a.x, a.ldx, a.x_kmajor = x.data_ptr(), ldx, int(x_kmajor)
+        a.y, a.ldy, a.y_kmajor = y.data_ptr(), ldy, int(y_kmajor)
+        a.epilogue = epilogue
+        a.out, a.ldo = out.data_ptr(), ldo
+        for f, t in (('out2', out2), ('bias', bias), ('colscale', colscale), ('resid', resid),
+                     ('rowscale', rowscale), ('aux', aux), ('pos', pos)):
+            setattr(a, f, t.data_ptr() if t is not None else None)
+        a.rows_per_scale, a.ldaux, a.pos_rows, a.split_k = rows_per_scale, ldaux, pos_rows, split_k
+        if row_map is not None:
+            a.out_row_div, a.out_row_hi, a.out_row_lo, a.out_row_off = row_map
+        self._add('vp_gemm_bf16', ctypes.byref(a),
+                  keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
+
+    def layernorm_fwd(self, x, gamma, beta, y_bf16, y_f32, mean, rstd, M, E, eps=1e-6):
+        _chk(x, torch.float32, 'x')
+        self._add('vp_layernorm_fwd', _p(x), _p(gamma), _p(beta), _p(y_bf16), _p(y_f32), _p(mean), _p(rstd),
+                  M, E, eps, keep=(x, gamma, beta, y_bf16, y_f32, mean, rstd))
+
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, rows_per_scale,
+                      dgamma, dbeta, dcolsum, M, E):
+        self._add('vp_layernorm_bwd', _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb),
+                  _p(rowscale), rows_per_scale, _p(dgamma), _p(dbeta), _p(dcolsum), M, E,
+                  keep=(dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, dgamma, dbeta, dcolsum))
+
+    def attention_fwd(self, qkv, out, lse, B, H, d, tokens, scale):
+        self._add('vp_attention_fwd', _p(qkv), _p(out), _p(lse), B, H, d, tokens, scale, keep=(qkv, out, lse))
+
+    def attention_bwd(self, qkv, out_fwd, dout, lse, dqkv, B, H, d, tokens, scale):
+        self._add('vp_attention_bwd', _p(qkv), _p(out_fwd), _p(dout), _p(lse), _p(dqkv), B, H, d, tokens, scale,
+                  keep=(qkv, out_fwd, dout, lse, dqkv))
+
+    def patch_im2col(self, img, col, B, C, H, W, patch, stride, pad):
+        _chk(img, torch.float32, 'img')
+        self._add('vp_patch_im2col', _p(img), _p(col), B, C, H, W, patch, stride, pad, keep=(img, col))
+
+    def strided_cast(self, src, dst, dims, strides):
+        dt = {torch.float32: _lib.VP_F32, torch.bfloat16: _lib.VP_BF16}
+        d = (ctypes.c_int * 4)(*dims)
+        s = (ctypes.c_long * 4)(*strides)
+        self._add('vp_strided_cast', _p(src), dt[src.dtype], _p(dst), dt[dst.dtype], ctypes.byref(d),
+                  ctypes.byref(s), keep=(src, dst, d, s))
+
+    def colsum(self, a, out, M, N, lda):
+        self._add('vp_colsum_bf16', _p(a), _p(out), M, N, lda, keep=(a, out))
+
+    def batch_sum(self, x, out, B, n):
+        self._add('vp_batch_sum_f32', _p(x), _p(out), B, n, keep=(x, out))
+
+    def deconv_phase_im2col(self, src, col, B, H, W, C, py, px):
+        self._add('vp_deconv_phase_im2col', _p(src), _p(col), B, H, W, C, py, px, keep=(src, col))
+
+    def deconv_out_gather16(self, dout, g, B, H, W, C):
+        self._add('vp_deconv_out_gather16', _p(dout), _p(g), B, H, W, C, keep=(dout, g))
+
+    def cast_f32_bf16(self, x, y, n):
+        self._add('vp_cast_f32_bf16', _p(x), _p(y), n, keep=(x, y))
+
+    def bn_stats(self, z, sums, M, C):
+        self._add('vp_bn_stats', _p(z), _p(sums), M, C, keep=(z, sums))
+
+    def bn_finalize(self, sums, M, C, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv):
+        self._add('vp_bn_finalize', _p(sums), M, C, _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
+                  _p(scale), _p(shift), _p(smean), _p(sinv),
+                  keep=(sums, gamma, beta, rmean, rvar, scale, shift, smean, sinv))
+
+    def bn_apply_relu(self, z, a, scale, shift, M, C):
+        self._add('vp_bn_apply_relu', _p(z), _p(a), _p(scale), _p(shift), M, C, keep=(z, a, scale, shift))
+
+    def bn_bwd(self, g, z, mean, invstd, gamma, dgamma, dbeta, dz, M, C):
+        self._add('vp_bn_bwd', _p(g), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz), M, C,
+                  keep=(g, z, mean, invstd, gamma, dgamma, dbeta, dz))
+
+    def heatmap_loss(self, heat, ldh, heat_nchw, target, tw, loss, dheat, B, K, HW, loss_weight):
+        self._add('vp_heatmap_loss', _p(heat), ldh, _p(heat_nchw), _p(target), _p(tw), _p(loss), _p(dheat),
+                  B, K, HW, loss_weight, keep=(heat, heat_nchw, target, tw, loss, dheat))
+
+    def argmax_rows(self, x, rows, L, idx, val):
+        self._add('vp_argmax_rows', _p(x), rows, L, _p(idx), _p(val), keep=(x, idx, val))
+
+    def sumsq(self, x, n, out):
+        self._add('vp_sumsq_f32', _p(x), n, _p(out), keep=(x, out))
+
+    def host(self, fn):
+        """A host-side closure (tiny torch glue on the current stream) inside the plan order."""
+        self.calls.append(('host', _Host(fn), ()))
+
+    def memset0(self, t):
+        """Zero a tensor on the plan's stream (torch's memset: plumbing, not compute)."""
+        self.calls.append(('zero_', _Zero(t), ()))
+        self.keep.append(t)
+
+
+class _Zero:
+    def __init__(self, t):
+        self.t = t
+
+    def __call__(self, _stream):
+        self.t.zero_()
+        return 0
+
+
+class _Host:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, _stream):
+        self.fn()
+        return 0
