@@ -1,0 +1,342 @@
+"""Per-kernel parity of the HIP kernels (through the C ABI) against plain torch fp32
+references on the same (bf16-rounded) inputs.  Integer-valued data makes the MFMA
+GEMM checks exact (products and f32 sums of small integers are exact), which catches
+any fragment-layout / transpose / swizzle mistake; random data checks rounding."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from vitpose_amd import _lib
+    _lib.lib()
+    return torch.device('cuda:0')
+
+
+def run(build):
+    from vitpose_amd.plan import Plan
+    p = Plan()
+    build(p)
+    p.run()
+    torch.cuda.synchronize()
+
+
+def ints(shape, dev, lo=-3, hi=4, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float().to(dev)
+
+
+def rnd(shape, dev, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize('xk,yk', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (192, 384, 128), (200, 136, 192), (384, 64, 256), (8, 8, 64)])
+def test_gemm_layouts_exact(dev, xk, yk, M, N, K):
+    from vitpose_amd import _lib
+    X = ints((M, K), dev, seed=1)          # asymmetric operands
+    Y = ints((N, K), dev, seed=2)
+    ref = X @ Y.t()
+    xs = (X.t() if xk else X).contiguous().bfloat16()
+    ys = (Y.t() if yk else Y).contiguous().bfloat16()
+    out = torch.full((M, N), float('nan'), device=dev)
+    run(lambda p: p.gemm(xs, ys, out, M, N, K, ldx=xs.shape[1], ldy=ys.shape[1], ldo=N, x_kmajor=xk, y_kmajor=yk,
+                         epilogue=_lib.VP_EPI_F32))
+    assert torch.equal(out, ref)
+
+
+def test_gemm_epilogues(dev):
+    from vitpose_amd import _lib
+    M, N, K, T = 384, 256, 128, 192
+    X, Y = rnd((M, K), dev, 3).bfloat16(), rnd((N, K), dev, 4, 0.1).bfloat16()
+    bias, cs = rnd((N,), dev, 5), rnd((N,), dev, 6)
+    acc = X.float() @ Y.float().t()
+    # BF16 with colscale + bias
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, colscale=cs))
+    torch.testing.assert_close(out.float(), (acc * cs + bias).bfloat16().float(), rtol=1e-2, atol=1e-2)
+    # SCALE_RELU
+    run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, colscale=cs,
+                         epilogue=_lib.VP_EPI_SCALE_RELU))
+    torch.testing.assert_close(out.float(), torch.relu(acc * cs + bias).bfloat16().float(), rtol=1e-2, atol=1e-2)
+    # GELU (+ pre-activation copy)
+    u = torch.empty_like(out)
+    run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, out2=u, epilogue=_lib.VP_EPI_GELU))
+    torch.testing.assert_close(u.float(), (acc + bias).bfloat16().float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.float(), torch.nn.functional.gelu(acc + bias), rtol=2e-2, atol=2e-2)
+    # RESID_F32 with per-sample row scale and position rows
+    resid, pos = rnd((M, N), dev, 7), rnd((T, N), dev, 8)
+    rs = torch.tensor([0.0, 1.0 / 0.7], device=dev)
+    o32 = torch.empty(M, N, device=dev)
+    run(lambda p: p.gemm(X, Y, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, resid=resid, rowscale=rs,
+                         rows_per_scale=T, pos=pos, pos_rows=T, epilogue=_lib.VP_EPI_RESID_F32))
+    ref = resid + rs.repeat_interleave(T)[:, None] * (acc + bias) + pos.repeat(2, 1)
+    torch.testing.assert_close(o32, ref, rtol=1e-4, atol=1e-4)
+    # DGELU / DRELU
+    aux = rnd((M, N), dev, 9).bfloat16()
+    run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, aux=aux, ldaux=N, epilogue=_lib.VP_EPI_DGELU))
+    a = aux.float().requires_grad_()
+    torch.nn.functional.gelu(a).sum().backward()
+    torch.testing.assert_close(out.float(), acc * a.grad, rtol=2e-2, atol=2e-2)
+    run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, aux=aux, ldaux=N, epilogue=_lib.VP_EPI_DRELU))
+    torch.testing.assert_close(out.float(), (acc * (aux.float() > 0)).bfloat16().float(), rtol=1e-2, atol=1e-2)
+    # ATOMIC split-K accumulate on top of existing values (integer data: exact)
+    Xi, Yi = ints((M, 512), dev, seed=10).bfloat16(), ints((N, 512), dev, seed=11).bfloat16()
+    o32.fill_(1.0)
+    run(lambda p: p.gemm(Xi, Yi, o32, M, N, 512, ldx=512, ldy=512, ldo=N, epilogue=_lib.VP_EPI_ATOMIC_F32, split_k=4))
+    assert torch.equal(o32, Xi.float() @ Yi.float().t() + 1.0)
+    # output row remap (sub-pixel phase placement): row i -> (i / W) * 4W + (i % W) * 2 + off
+    W = 12
+    big = torch.zeros(4 * M, N, device=dev)
+    run(lambda p: p.gemm(Xi, Yi, big, M, N, 512, ldx=512, ldy=512, ldo=N, epilogue=_lib.VP_EPI_F32,
+                         row_map=(W, 4 * W, 2, 2 * W + 1)))
+    i = torch.arange(M, device=dev)
+    rows = (i // W) * 4 * W + (i % W) * 2 + 2 * W + 1
+    assert torch.equal(big[rows], Xi.float() @ Yi.float().t())
+    assert big.abs().sum() == big[rows].abs().sum()
+
+
+def test_gemm_rejects_bad_args(dev):
+    from vitpose_amd.plan import KernelError
+    X = torch.zeros(64, 100, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(64, 64, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(KernelError):
+        run(lambda p: p.gemm(X, X, out, 64, 64, 100, ldx=100, ldy=100, ldo=64))  # K % 64 != 0
+
+
+@pytest.mark.parametrize('E', [64, 384, 768, 1280])
+def test_layernorm_fwd_bwd(dev, E):
+    M, T = 4 * 192 + 5, 192
+    x = rnd((M, E), dev, 1) * 2 + 0.5
+    g, b = 1 + 0.2 * rnd((E,), dev, 2), 0.1 * rnd((E,), dev, 3)
+    y, y32 = torch.empty(M, E, device=dev, dtype=torch.bfloat16), torch.empty(M, E, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    run(lambda p: p.layernorm_fwd(x, g, b, y, y32, mean, rstd, M, E))
+    xr = x.clone().requires_grad_()
+    gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr, (E,), gr, br, 1e-6)
+    torch.testing.assert_close(y32, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y.float(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(mean, x.mean(1), rtol=1e-5, atol=1e-5)
+    dy = rnd((M, E), dev, 4).bfloat16()
+    dres = rnd((M, E), dev, 5)
+    nb = (M + T - 1) // T
+    rs = torch.rand(nb, device=dev) + 0.5
+    dx, dxb = torch.empty(M, E, device=dev), torch.empty(M, E, device=dev, dtype=torch.bfloat16)
+    dg, db, dc = torch.ones(E, device=dev), torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    run(lambda p: p.layernorm_bwd(dy, x, mean, rstd, g, dres, dx, dxb, rs, T, dg, db, dc, M, E))
+    ref.backward(dy.float())
+    dx_ref = xr.grad + dres
+    torch.testing.assert_close(dx, dx_ref, rtol=1e-4, atol=1e-4)
+    scaled = dx_ref * rs.repeat_interleave(T)[:M, None]
+    torch.testing.assert_close(dxb.float(), scaled.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(dg - 1.0, gr.grad, rtol=1e-3, atol=2e-3)  # accumulates onto the 1s
+    torch.testing.assert_close(db, br.grad, rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(dc, scaled.sum(0), rtol=1e-3, atol=5e-3)
+
+
+def _attn_ref(qkv, B, H, d, scale):
+    T = 192
+    q, k, v = qkv.float().reshape(B, T, 3, H, d).permute(2, 0, 3, 1, 4)
+    s = (q * scale) @ k.transpose(-2, -1)
+    p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B * T, H * d), torch.logsumexp(s, -1).reshape(B * H, T)
+
+
+@pytest.mark.parametrize('H,d', [(2, 32), (3, 64), (12, 64)])
+def test_attention_fwd_bwd(dev, H, d):
+    B, T, E = 2, 192, H * d
+    qkv = (rnd((B * T, 3 * E), dev, 1) * 1.5).bfloat16()
+    scale = d ** -0.5
+    out = torch.empty(B * T, E, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B * H, T, device=dev)
+    run(lambda p: p.attention_fwd(qkv, out, lse, B, H, d, T, scale))
+    qr = qkv.float().requires_grad_()
+    ref, lse_ref = _attn_ref(qr, B, H, d, scale)
+    torch.testing.assert_close(lse, lse_ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    dout = rnd((B * T, E), dev, 2).bfloat16()
+    dqkv = torch.full((B * T, 3 * E), float('nan'), device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.attention_bwd(qkv, out, dout, lse, dqkv, B, H, d, T, scale))
+    ref.backward(dout.float())
+    err = (dqkv.float() - qr.grad).abs().max().item()
+    assert err < 3e-2 * max(1.0, qr.grad.abs().max().item()), err
+    rel = (dqkv.float() - qr.grad).norm() / qr.grad.norm()
+    assert rel < 2e-2, rel
+
+
+def test_attention_integer_exact_layout(dev):
+    """Uniform scores (q = 0) make P = 1/192 exactly: out = column means of V, which pins
+    the V transposed-read / P*V operand pairing independent of softmax rounding."""
+    B, H, d, T = 1, 2, 64, 192
+    E = H * d
+    qkv = torch.zeros(B * T, 3 * E, device=dev)
+    qkv[:, 2 * E:] = ints((B * T, E), dev, -8, 9, seed=3)
+    qkv[:, E:2 * E] = ints((B * T, E), dev, seed=4)
+    out = torch.empty(B * T, E, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.attention_fwd(qkv.bfloat16(), out, None, B, H, d, T, d ** -0.5))
+    ref = qkv[:, 2 * E:].mean(0, keepdim=True).expand(T, E)
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_patch_im2col_and_casts(dev):
+    B = 2
+    img = rnd((B, 3, 256, 192), dev, 1)
+    col = torch.empty(B * 192, 768, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.patch_im2col(img, col, B, 3, 256, 192, 16, 16, 2))
+    ref = torch.nn.functional.unfold(img, 16, padding=2, stride=16).transpose(1, 2).reshape(B * 192, 768)
+    assert torch.equal(col.float(), ref.bfloat16().float())
+    # strided cast: NCHW <-> token-major permute
+    x = rnd((B, 192, 64), dev, 2)
+    o = torch.empty(B, 64, 192, device=dev)
+    run(lambda p: p.strided_cast(x, o, (1, B, 64, 192), (0, 192 * 64, 1, 64)))
+    assert torch.equal(o, x.permute(0, 2, 1).contiguous())
+    a = rnd((777, 264), dev, 3).bfloat16()
+    cs = torch.ones(264, device=dev)
+    run(lambda p: p.colsum(a, cs, 777, 264, 264))
+    torch.testing.assert_close(cs, a.float().sum(0) + 1, rtol=1e-4, atol=1e-3)
+    xs = rnd((3, 192 * 64), dev, 4)
+    bs = torch.empty(192 * 64, device=dev)
+    run(lambda p: p.batch_sum(xs, bs, 3, 192 * 64))
+    torch.testing.assert_close(bs, xs.sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_deconv_as_subpixel_gemms(dev):
+    """ConvTranspose2d(k4,s2,p1) forward, data gradient and weight gradient via the im2col views."""
+    from vitpose_amd import _lib
+    B, H, W, Ci, Co = 2, 16, 12, 64, 64
+    x = ints((B, Ci, H, W), dev, -2, 3, seed=1)
+    wt = ints((Ci, Co, 4, 4), dev, -2, 3, seed=2)
+    ref = torch.nn.functional.conv_transpose2d(x, wt, stride=2, padding=1)
+    xcl = x.permute(0, 2, 3, 1).contiguous().bfloat16().view(B * H * W, Ci)
+    out = torch.full((B * 4 * H * W, Co), float('nan'), device=dev)
+    col = torch.empty(B * H * W, 4 * Ci, device=dev, dtype=torch.bfloat16)
+    wph = torch.empty(4, Co, 4 * Ci, device=dev, dtype=torch.bfloat16)
+
+    def fwd(p):
+        for py in range(2):
+            for px in range(2):
+                p.strided_cast(wt.view(-1)[(1 - py) * 4 + (1 - px):], wph[py * 2 + px], (Co, 2, 2, Ci),
+                               (16, 8, 2, Co * 16))
+                p.deconv_phase_im2col(xcl, col, B, H, W, Ci, py, px)
+                p.gemm(col, wph[py * 2 + px], out, B * H * W, Co, 4 * Ci, ldx=4 * Ci, ldy=4 * Ci, ldo=Co,
+                       epilogue=_lib.VP_EPI_F32, row_map=(W, 4 * W, 2, py * 2 * W + px))
+    run(fwd)
+    assert torch.equal(out.view(B, 2 * H, 2 * W, Co).permute(0, 3, 1, 2), ref)
+    # backward
+    dout = ints((B, Co, 2 * H, 2 * W), dev, -2, 3, seed=3)
+    xr, wr = x.clone().requires_grad_(), wt.clone().requires_grad_()
+    torch.nn.functional.conv_transpose2d(xr, wr, stride=2, padding=1).backward(dout)
+    dcl = dout.permute(0, 2, 3, 1).contiguous().bfloat16().view(-1, Co)
+    G = torch.empty(B * H * W, 16 * Co, device=dev, dtype=torch.bfloat16)
+    wd = torch.empty(Ci, 16 * Co, device=dev, dtype=torch.bfloat16)
+    dx = torch.empty(B * H * W, Ci, device=dev)
+    dwd = torch.zeros(Ci, 16 * Co, device=dev)
+
+    def bwd(p):
+        p.strided_cast(wt, wd, (Ci, 16, Co, 1), (Co * 16, 1, 16, 0))
+        p.deconv_out_gather16(dcl, G, B, H, W, Co)
+        p.gemm(G, wd, dx, B * H * W, Ci, 16 * Co, ldx=16 * Co, ldy=16 * Co, ldo=Ci, epilogue=_lib.VP_EPI_F32)
+        p.gemm(xcl, G, dwd, Ci, 16 * Co, B * H * W, ldx=Ci, ldy=16 * Co, ldo=16 * Co, x_kmajor=True, y_kmajor=True,
+               epilogue=_lib.VP_EPI_ATOMIC_F32, split_k=3)
+    run(bwd)
+    assert torch.equal(dx.view(B, H, W, Ci).permute(0, 3, 1, 2), xr.grad)
+    assert torch.equal(dwd.view(Ci, 16, Co).permute(0, 2, 1).reshape(Ci, Co, 4, 4), wr.grad)
+
+
+def test_batchnorm_relu_fwd_bwd(dev):
+    M, C = 2 * 32 * 24, 256
+    z = (rnd((M, C), dev, 1) * 1.5 + 0.3).bfloat16()
+    gamma, beta = 1 + 0.2 * rnd((C,), dev, 2), 0.1 * rnd((C,), dev, 3)
+    rm, rv = rnd((C,), dev, 4) * 0.1, torch.rand(C, device=dev) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    sums = torch.zeros(2 * C, device=dev)
+    scale, shift, sm, si = (torch.empty(C, device=dev) for _ in range(4))
+    a = torch.empty_like(z)
+
+    def fwd(p):
+        p.bn_stats(z, sums, M, C)
+        p.bn_finalize(sums, M, C, gamma, beta, rm, rv, 0.1, 1e-5, scale, shift, sm, si)
+        p.bn_apply_relu(z, a, scale, shift, M, C)
+    run(fwd)
+    zr = z.float().requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = torch.relu(torch.nn.functional.batch_norm(zr, rm0, rv0, gr, br, True, 0.1, 1e-5))
+    torch.testing.assert_close(a.float(), ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(rm, rm0, rtol=1e-4, atol=1e-5)   # batch_norm updated rm0 in place
+    torch.testing.assert_close(rv, rv0, rtol=1e-4, atol=1e-5)
+    da = rnd((M, C), dev, 5)
+    ref.backward(da)
+    gmask = (da * (a.float() > 0)).bfloat16()
+    dg, db, dz = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.empty_like(z)
+    run(lambda p: p.bn_bwd(gmask, z, sm, si, gamma, dg, db, dz, M, C))
+    torch.testing.assert_close(dg, gr.grad, rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(db, br.grad, rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(dz.float(), zr.grad, rtol=3e-2, atol=3e-2)
+    # eval mode: running statistics
+    run(lambda p: p.bn_finalize(None, M, C, gamma, beta, rm, rv, 0.1, 1e-5, scale, shift, None, None))
+    torch.testing.assert_close(scale, gamma / torch.sqrt(rv + 1e-5), rtol=1e-5, atol=1e-6)
+
+
+def test_heatmap_loss_and_argmax(dev):
+    B, K, H, W, LD = 3, 17, 64, 48, 64
+    heat_nchw = rnd((B, K, H, W), dev, 1)
+    heat = torch.zeros(B * H * W, LD, device=dev)
+    heat[:, :K] = heat_nchw.permute(0, 2, 3, 1).reshape(-1, K)
+    target = torch.rand(B, K, H, W, device=dev)
+    tw = (torch.rand(B, K, device=dev) > 0.3).float()
+    out = torch.empty(B, K, H, W, device=dev)
+    loss = torch.zeros(1, device=dev)
+    dheat = torch.full((B * H * W, LD), float('nan'), device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.heatmap_loss(heat, LD, out, target, tw, loss, dheat, B, K, H * W, 1.0))
+    assert torch.equal(out, heat_nchw)
+    pr = heat_nchw.clone().requires_grad_()
+    w = tw.view(B, K, 1, 1)
+    ref = sum(torch.nn.functional.mse_loss(pr[:, k] * w[:, k], target[:, k] * w[:, k]) for k in range(K)) / K
+    ref.backward()
+    torch.testing.assert_close(loss[0], ref, rtol=1e-5, atol=1e-7)
+    dref = pr.grad.permute(0, 2, 3, 1).reshape(-1, K)
+    torch.testing.assert_close(dheat[:, :K].float(), dref.bfloat16().float(), rtol=1e-2, atol=1e-9)
+    assert dheat[:, K:].float().abs().max() == 0
+    idx = torch.empty(B * K, device=dev, dtype=torch.int32)
+    val = torch.empty(B * K, device=dev)
+    run(lambda p: p.argmax_rows(heat_nchw, B * K, H * W, idx, val))
+    flat = heat_nchw.view(B * K, -1)
+    assert torch.equal(idx.long(), flat.argmax(1))
+    assert torch.equal(val, flat.max(1).values)
+
+
+def test_adamw_matches_torch(dev):
+    from vitpose_amd.engine import ParamStore
+    from vitpose_amd.optim import FlatAdamW
+    shapes = [('backbone.blocks.0.attn.qkv.weight', (96, 40)), ('backbone.blocks.0.attn.qkv.bias', (97,)),
+              ('keypoint_head.final_layer.weight', (17, 33, 1, 1))]
+    st = ParamStore(shapes, dev)
+    ref = []
+    for i, (n, s) in enumerate(shapes):
+        st.view(n).copy_(rnd(s, dev, i))
+        ref.append(st.view(n).clone().requires_grad_())
+    groups = {shapes[0][0]: dict(lr_scale=0.5, weight_decay=0.1), shapes[1][0]: dict(lr_scale=0.5, weight_decay=0.0),
+              shapes[2][0]: dict(lr_scale=1.0, weight_decay=0.1)}
+    opt = FlatAdamW(st, groups, lr=1e-2, max_grad_norm=1.0)
+    topt = torch.optim.AdamW([dict(params=[ref[0]], lr=5e-3, weight_decay=0.1),
+                              dict(params=[ref[1]], lr=5e-3, weight_decay=0.0),
+                              dict(params=[ref[2]], lr=1e-2, weight_decay=0.1)], lr=1e-2)
+    for step in range(3):
+        for i, (n, s) in enumerate(shapes):
+            gr = rnd(s, dev, 10 * step + i) * 3
+            st.gview(n).copy_(gr)
+            ref[i].grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        topt.step()
+        opt.step()
+    for i, (n, s) in enumerate(shapes):
+        torch.testing.assert_close(st.view(n), ref[i].detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(st.hview(n).float(), ref[i].detach().bfloat16().float(), rtol=1e-2, atol=1e-3)

@@ -1,0 +1,199 @@
+"""End-to-end parity of the HIP path (PoseEngine, through the C ABI) against
+  (a) the golden vectors produced by the reference's own source files, and
+  (b) the CPU oracle on the same seeded inputs.
+
+Tolerances.  The path computes in bf16 (MFMA operands, bf16 activations between
+kernels; f32 accumulation, f32 residual stream / LayerNorm / softmax statistics).
+The north-star tolerance "heatmaps within 1e-3 max-abs of the reference CPU forward"
+is asserted on the reference's own weight initialisation (trunc_normal 0.02 backbone,
+std=0.001 head: heatmap magnitudes ~1e-4..1e-3).  On the non-degenerate synthetic
+weights of the golden fixtures (heatmaps O(1)) bf16 rounding gives ~1e-2 max-abs; that
+bound is asserted separately as a relative error so the number is visible.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitpose_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOY = dict(img_size=(256, 192), patch_size=16, in_chans=3, embed_dim=64, depth=2, num_heads=2,
+           mlp_ratio=4, qkv_bias=True, ratio=1, last_norm=True, drop_path_rate=0.0)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def make_engine(vcfg, hcfg, bb, hd, dev):
+    from vitpose_amd.pose_engine import PoseEngine
+    eng = PoseEngine(vcfg, hcfg, dev)
+    sd = {'backbone.' + k: v for k, v in bb.items()}
+    sd.update({'keypoint_head.' + k: v for k, v in hd.items()})
+    eng.load_state_dict(sd)
+    return eng
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return ((a - b).norm() / b.norm()).item(), (a - b).abs().max().item()
+
+
+def test_toy_backbone_tokens(dev, golden_dir):
+    from vitpose_amd.engine import ParamStore, VitRunner, Workspace, vit_param_shapes
+    from vitpose_amd.plan import Plan
+    g = np.load(os.path.join(golden_dir, 'toy_vit.npz'))
+    sd = O.synth_vit_weights(TOY, seed=10)
+    img, _, _ = O.synth_batch(2, seed=11)
+    st = ParamStore(vit_param_shapes(TOY), dev)
+    st.load(sd)
+    st.half.copy_(st.data)
+    vr = VitRunner(TOY, st)
+    vr.refresh_derived()
+    ws = Workspace(dev)
+    tok = torch.empty(2 * 192, 64, device=dev)
+    plan = Plan()
+    vr.record_forward(plan, ws, img.to(dev), 2, training=True, tokens_f32=tok)
+    plan.run()
+    torch.cuda.synchronize()
+    feat = tok.view(2, 192, 64).permute(0, 2, 1).reshape(2, 64, 16, 12).cpu()
+    # stage-by-stage against the reference taps of block 0, image 0
+    for name, buf, width in (('block_in', 'x_in.0', 64), ('ln1', 'xn1.0', 64), ('qkv', 'qkv.0', 192),
+                             ('attn_o', 'ao.0', 64), ('fc1_pre', 'u.0', 256), ('fc1_act', 'h.0', 256),
+                             ('block_out', 'x_in.1', 64)):
+        got = ws.bufs[buf].float().view(2, 192, width)[0].cpu()
+        rel, mx = relerr(got, g[name][0])
+        assert rel < 1.5e-2, (name, rel, mx)
+    rel, mx = relerr(feat, g['feat'])
+    assert rel < 2e-2, (rel, mx)
+
+
+def test_vitpose_s_classic_eval_vs_reference_golden(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'vitpose_s_classic_eval.npz'))
+    vcfg, hc = O.vit_cfg('S'), O.classic_head_cfg(384)
+    eng = make_engine(vcfg, hc, O.synth_vit_weights(vcfg, seed=20), O.synth_head_weights(hc, seed=21), dev)
+    img, _, _ = O.synth_batch(2, seed=22)
+    heat = eng.infer(img.to(dev)).cpu()
+    assert heat.shape == (2, 17, 64, 48)
+    rel, mx = relerr(heat, g['heat'])
+    print(f'ViTPose-S classic eval, O(1) heatmaps (|ref|max {np.abs(g["heat"]).max():.2f}): rel {rel:.2e} maxabs {mx:.2e}')
+    assert rel < 3e-2 and mx < 0.15, (rel, mx)
+
+
+def test_reference_init_heatmaps_within_1e3(dev):
+    """North-star gate: max-abs 1e-3 against the reference CPU forward (here the oracle,
+    which the goldens pin to the reference) with the reference's own initialisation."""
+    vcfg, hc = O.vit_cfg('S'), O.classic_head_cfg(384)
+    g = torch.Generator().manual_seed(7)
+    bb = {}
+    for n, s in O.vit_param_shapes(vcfg):
+        if n.endswith('norm1.weight') or n.endswith('norm2.weight') or n == 'last_norm.weight':
+            bb[n] = torch.ones(s)
+        elif n.endswith('.bias'):
+            bb[n] = torch.zeros(s)
+        elif n == 'patch_embed.proj.weight':   # nn.Conv2d default init (kaiming uniform a=sqrt(5))
+            bound = 1.0 / np.sqrt(s[1] * s[2] * s[3])
+            bb[n] = (torch.rand(s, generator=g) * 2 - 1) * bound
+        else:                                  # trunc_normal_(std=.02) (vit.py:245,297)
+            bb[n] = torch.nn.init.trunc_normal_(torch.empty(s), std=.02, generator=g)
+    hd = {}
+    for n, s in O.head_param_shapes(hc):       # normal_init(std=0.001), BN (1, 0) (simple_head.py:339-350)
+        if n.endswith('running_var') or (n.endswith('.weight') and len(s) == 1):
+            hd[n] = torch.ones(s)
+        elif len(s) == 1:
+            hd[n] = torch.zeros(s)
+        else:
+            hd[n] = torch.randn(s, generator=g) * 0.001
+    eng = make_engine(vcfg, hc, bb, hd, dev)
+    img, _, _ = O.synth_batch(2, seed=8)
+    heat = eng.infer(img.to(dev)).cpu()
+    with torch.no_grad():
+        ref = O.topdown_forward(bb, hd, img, vcfg, hc)
+    mx = (heat - ref).abs().max().item()
+    print(f'reference-init heatmaps: |ref|max {ref.abs().max():.2e}, max-abs diff {mx:.2e}')
+    assert mx < 1e-3
+    assert mx < 0.05 * ref.abs().max().item()  # and not vacuously: within 5 % of the signal
+
+
+def test_vitpose_s_train_step_vs_reference_golden(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'vitpose_s_train.npz'))
+    vcfg = O.vit_cfg('S', drop_path_rate=0.3)
+    hc = O.classic_head_cfg(384)
+    eng = make_engine(vcfg, hc, O.synth_vit_weights(vcfg, seed=30), O.synth_head_weights(hc, seed=31), dev)
+    img, target, tw = O.synth_batch(4, seed=32)
+    rates = O.drop_path_rates(vcfg)
+    draws = torch.from_numpy(g['dp_draws'])
+    dp = torch.ones(vcfg['depth'], 2, 4)
+    for i in range(1, vcfg['depth']):
+        dp[i, 0] = O.drop_path_scale(draws[2 * (i - 1)], rates[i])
+        dp[i, 1] = O.drop_path_scale(draws[2 * (i - 1) + 1], rates[i])
+    loss, heat = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), dp_scales=dp.to(dev))
+    torch.cuda.synchronize()
+    rel, mx = relerr(heat[:, ::4], g['heat_sub'])
+    print(f'train heat: rel {rel:.2e} max {mx:.2e}; loss {loss.item():.6f} vs {float(g["loss"]):.6f}')
+    assert rel < 3e-2
+    assert abs(loss.item() - float(g['loss'])) < 2e-2 * float(g['loss'])
+    worst = {}
+    for k in g.files:
+        if k.startswith('g.'):
+            got = eng.store.gview('backbone.' + k[2:])
+        elif k.startswith('gs.'):
+            got = eng.store.gview('backbone.' + k[3:]).flatten(1)[::16, ::4]
+        elif k.startswith('gh.'):
+            got = eng.store.gview('keypoint_head.' + k[3:])
+        elif k.startswith('ghs.'):
+            got = eng.store.gview('keypoint_head.' + k[4:]).flatten(1)[::8, ::16]
+        else:
+            continue
+        worst[k] = relerr(got.reshape(g[k].shape), g[k])[0]
+    print('grad rel errors:', {k: f'{v:.1e}' for k, v in worst.items()})
+    assert max(worst.values()) < 8e-2, worst
+    # BN running statistics were updated with the batch statistics
+    for n, k in (('deconv_layers.1.running_mean', 'bn1_mean'), ('deconv_layers.1.running_var', 'bn1_var'),
+                 ('deconv_layers.4.running_mean', 'bn4_mean'), ('deconv_layers.4.running_var', 'bn4_var')):
+        rel, _ = relerr(eng.buffers['keypoint_head.' + n], g[k])
+        assert rel < 2e-2, (n, rel)
+
+
+def test_train_step_updates_weights_like_torch_adamw(dev):
+    """One full step (fwd + bwd + clip + layer-decay AdamW) on the toy model against the oracle
+    differentiated by torch autograd and stepped by torch.optim.AdamW with the same groups."""
+    from vitpose_amd.optim import layer_decay_param_groups
+    hc = dict(O.classic_head_cfg(64))
+    bb, hd = O.synth_vit_weights(TOY, seed=1), O.synth_head_weights(hc, seed=2)
+    eng = make_engine(TOY, hc, bb, hd, dev)
+    eng.setup_optimizer(lr=1e-3, weight_decay=0.1, layer_decay_rate=0.75, max_grad_norm=1.0)
+    img, target, tw = O.synth_batch(2, seed=3)
+    eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    params = {('backbone.' + k): v.clone().requires_grad_() for k, v in bb.items()}
+    hparams = {k: v.clone() for k, v in hd.items()}
+    for k, v in hparams.items():
+        if 'running' not in k:
+            params['keypoint_head.' + k] = v.requires_grad_()
+    bbp = {k[len('backbone.'):]: v for k, v in params.items() if k.startswith('backbone.')}
+    heat = O.head_forward(hparams, O.vit_forward(bbp, img, TOY), hc, training=True)
+    O.joints_mse_loss(heat, target, tw).backward()
+    groups = layer_decay_param_groups([(n, tuple(p.shape)) for n, p in params.items()], TOY['depth'], 0.75, 1e-3, 0.1)
+    topt = torch.optim.AdamW([dict(params=[p], lr=groups[n]['lr'], weight_decay=groups[n]['weight_decay'])
+                              for n, p in params.items()], lr=1e-3)
+    before = {n: p.detach().clone() for n, p in params.items()}
+    torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+    topt.step()
+    # compare the UPDATE direction (Adam's first step is lr * sign-like, so compare deltas)
+    num = den = 0.0
+    for n, p in params.items():
+        d_ref = (p.detach() - before[n]).flatten()
+        d_got = (eng.store.view(n).cpu() - before[n]).flatten()
+        num += (d_ref - d_got).pow(2).sum().item()
+        den += d_ref.pow(2).sum().item()
+    rel = (num / den) ** 0.5
+    print(f'relative error of the first AdamW update over all parameters: {rel:.3e}')
+    assert rel < 0.15
