@@ -1,0 +1,100 @@
+"""Batch-sharded data parallelism: one process per GPU, parameters replicated, the flat
+gradient buffer all-reduced over RCCL (torch.distributed backend "nccl") in a few large
+contiguous buckets that are launched from inside the backward plan, in the order the
+backward pass completes them (head first, then blocks depth-1 .. 0), on a side stream so the
+exchange overlaps the remaining backward kernels.
+
+This replaces the reference's MMDistributedDataParallel wrapper (mmpose/apis/train.py:116-133:
+bucketed gradient all-reduce, averaged over ranks, `broadcast_buffers=False` so BatchNorm
+statistics stay per shard).  The per-iteration all-reduce of the logged loss scalars
+(mmpose/models/detectors/base.py:66-72) is available as `reduce_scalars`, to be called only on
+logging iterations.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, store, backbone_prefix='backbone.', head_prefix='keypoint_head.', depth=12,
+                 blocks_per_bucket=3, process_group=None):
+        self.store = store
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.on_gpu = store.device.type == 'cuda'
+        self.stream = torch.cuda.Stream(device=store.device) if self.on_gpu else None
+        self.pending = []
+        self.ready_events = []
+        # flat layout (forward order): pos/patch, block 0 .. depth-1, last_norm, head
+        off = store.offsets
+        end = store.numel
+
+        def start_of(prefix):
+            for n in store.names:
+                if n.startswith(prefix):
+                    return off[n]
+            return end
+        self.bounds = {}  # block index i -> offset where block i starts
+        for i in range(depth):
+            self.bounds[i] = start_of(f'{backbone_prefix}blocks.{i}.')
+        # trigger points during backward: after block i is finished, everything from block i to the
+        # end of the previously sent region is final
+        self.triggers = {}
+        hi = end
+        i = depth - 1
+        while i > 0:
+            lo_blk = max(1, i - blocks_per_bucket + 1)
+            self.triggers[lo_blk] = (self.bounds[lo_blk], hi)
+            hi = self.bounds[lo_blk]
+            i = lo_blk - 1
+        self.tail = (0, hi)  # block 0 + patch/pos embedding: sent when backward ends
+
+    # -- called from plan.host closures (i.e. in stream order of the compute stream) --
+    def _launch(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        g = self.store.grad[lo:hi]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append(w)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def after_block(self, plan, i):
+        if i in self.triggers:
+            lo, hi = self.triggers[i]
+            plan.host(lambda lo=lo, hi=hi: self._launch(lo, hi))
+
+    def finish(self, plan):
+        lo, hi = self.tail
+        plan.host(lambda: self._launch(lo, hi))
+        plan.host(self.wait)
+
+    def wait(self):
+        """Make the compute stream wait for every outstanding bucket."""
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+
+def reduce_scalars(values: torch.Tensor, group=None) -> torch.Tensor:
+    """Average a small tensor of logged scalars over ranks (one collective for all of them)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+        values /= dist.get_world_size(group)
+    return values
+
+
+def shard_batch(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous equal shards of the global batch (weak scaling: n_total = world * per_gpu)."""
+    per = n_total // world
+    return rank * per, (rank + 1) * per

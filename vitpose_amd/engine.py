@@ -249,7 +249,7 @@ class VitRunner:
 
     # -- backward (training workspaces of record_forward(training=True) required) --
     def record_backward(self, plan: Plan, ws: Workspace, dfeat: torch.Tensor, B: int,
-                        dp: Optional[torch.Tensor] = None):
+                        dp: Optional[torch.Tensor] = None, after_block=None):
         """dfeat = bf16 [B*T][E] gradient wrt the final feature.  Accumulates into store.grad."""
         E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
         ATOM = _lib.VP_EPI_ATOMIC_F32
@@ -314,6 +314,9 @@ class VitRunner:
                                dx, other, dxb, dp_scale(i - 1, 1), T, self.g(b + 'norm1.weight'),
                                self.g(b + 'norm1.bias'), nxt_bias, M, E)
             dx, other = other, dx
+            if after_block is not None and i > 0:
+                # every gradient of blocks >= i is final here except fc2.bias of block i-1
+                after_block(plan, i)
         # ---- patch embedding + position embedding
         plan.gemm(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
                   ldo=self.Kpe, x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(E, self.Kpe, M))

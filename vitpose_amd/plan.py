@@ -37,12 +37,32 @@ class Plan:
         self.L = _lib.lib()
         self.calls = []     # (name, cfunc, args)
         self.keep = []      # tensors / ctypes objects that must outlive the plan
+        self.tags = {}      # call index -> (x_kmajor, y_kmajor, epilogue, M, N, K) of GEMM launches
 
     # -- replay --
     def run(self, stream=None):
         s = c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
         for name, fn, args in self.calls:
             rc = fn(*args, s)
+            if rc != 0:
+                raise KernelError(f'{name} failed with status {rc}')
+
+    def run_timed(self, timers):
+        """Replay with a HIP event pair around every GEMM launch (events are recorded on the
+        stream the kernels are launched on).  `timers` is a list that receives
+        (gemm_tag, start_event, end_event); read elapsed times after a synchronize."""
+        st = torch.cuda.current_stream()
+        s = c_void_p(st.cuda_stream)
+        for i, (name, fn, args) in enumerate(self.calls):
+            tag = self.tags.get(i)
+            if tag is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                rc = fn(*args, s)
+                e1.record(st)
+                timers.append((tag, e0, e1))
+            else:
+                rc = fn(*args, s)
             if rc != 0:
                 raise KernelError(f'{name} failed with status {rc}')
 
@@ -70,6 +90,7 @@ class Plan:
         a.rows_per_scale, a.ldaux, a.pos_rows, a.split_k = rows_per_scale, ldaux, pos_rows, split_k
         if row_map is not None:
             a.out_row_div, a.out_row_hi, a.out_row_lo, a.out_row_off = row_map
+        self.tags[len(self.calls)] = (int(x_kmajor), int(y_kmajor), epilogue, M, N, K)
         self._add('vp_gemm_bf16', ctypes.byref(a),
                   keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
 

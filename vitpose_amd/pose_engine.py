@@ -41,6 +41,16 @@ class PoseEngine:
         self.prep_derived = Plan()  # after an optimizer step the bf16 mirror is already fresh
         self.head.record_weight_prep(self.prep_derived)
         self.optimizer = None
+        self.comm = None
+
+    def enable_ddp(self, process_group=None, blocks_per_bucket=3):
+        """Batch-sharded data parallelism: all-reduce the flat gradient buffer in buckets launched
+        from inside the backward plan (call before the first training step)."""
+        from .ddp import GradBuckets
+        self.comm = GradBuckets(self.store, depth=self.vit.depth, blocks_per_bucket=blocks_per_bucket,
+                                process_group=process_group)
+        self.plans = {k: v for k, v in self.plans.items() if k[0] != 'train'}
+        return self.comm
 
     # ---- weights ----
     def named_shapes(self):
@@ -106,12 +116,16 @@ class PoseEngine:
                                              want_grad=True, loss_weight=self.loss_weight)
             self.n_fwd_calls = len(plan)
             dfeat = self.head.record_backward(plan, ws, feat, dheat, B)
-            self.vit.record_backward(plan, ws, dfeat, B, dp=io['dp'])
+            comm = self.comm
+            self.vit.record_backward(plan, ws, dfeat, B, dp=io['dp'],
+                                     after_block=comm.after_block if comm is not None else None)
+            if comm is not None:
+                comm.finish(plan)
             self.plans[key] = (plan, io)
         return self.plans[key]
 
     def forward_backward(self, img, target, target_weight, drop_path: bool = True, dp_scales=None,
-                         generator=None):
+                         generator=None, timers=None):
         """One training forward + backward.  Gradients land in self.store.grad (zeroed first);
         returns (loss [1] device tensor, heatmaps [B,K,H,W] device tensor; both are plan-owned)."""
         B = img.shape[0]
@@ -125,7 +139,10 @@ class PoseEngine:
             self.vit.sample_drop_path(io['dp'], generator)
         else:
             io['dp'].fill_(1.0)
-        plan.run()
+        if timers is not None:
+            plan.run_timed(timers)
+        else:
+            plan.run()
         return io['loss'], io['heat']
 
     def setup_optimizer(self, lr=5e-4, betas=(0.9, 0.999), weight_decay=0.1, layer_decay_rate=0.75,
@@ -136,6 +153,8 @@ class PoseEngine:
         self.optimizer = FlatAdamW(self.store, groups, lr, betas, 1e-8, max_grad_norm)
         return self.optimizer
 
-    def optimizer_step(self, lr=None, grad_scale=1.0):
+    def optimizer_step(self, lr=None, grad_scale=None):
+        if grad_scale is None:
+            grad_scale = self.comm.grad_scale if self.comm is not None else 1.0
         self.optimizer.step(lr, grad_scale)
         self.refresh_weights(after_optimizer_step=True)
