@@ -48,7 +48,7 @@ enum {
     VP_EPI_GELU = 1,       /* out2(bf16, optional) = u = acc + bias; out(bf16) = gelu_erf(u)    */
     VP_EPI_RESID_F32 = 2,  /* out(f32) = resid + rowscale[i/rows_per_scale]*(acc+bias) + pos[i%pos_rows] */
     VP_EPI_DGELU = 3,      /* out(bf16) = acc * gelu_erf'(aux(bf16))                            */
-    VP_EPI_ATOMIC_F32 = 4, /* out(f32) += acc   (atomic; split_k >= 1)                          */
+    VP_EPI_SPLITK_F32 = 4, /* K slice z of split_k writes its partial sums to out + z*split_stride (f32) */
     VP_EPI_F32 = 5,        /* out(f32) = acc + bias                                             */
     VP_EPI_SCALE_RELU = 6, /* out(bf16) = relu(acc*colscale + bias)                             */
     VP_EPI_DRELU = 7       /* out(bf16) = acc * (aux(bf16) > 0)                                 */
@@ -69,13 +69,18 @@ typedef struct vp_gemm_args {
     const void* aux; int ldaux;  /* [M][ldaux] bf16 for DGELU / DRELU */
     const float* pos;            /* [pos_rows][ldo] f32 or NULL */
     int pos_rows;
-    int split_k;                 /* ATOMIC_F32 only: number of K slices (grid.y) */
+    int split_k;                 /* SPLITK_F32 only: number of K slices (grid.y), <= K/64 */
+    long split_stride;           /* SPLITK_F32 only: elements between the slices' slabs (>= M*ldo) */
     /* optional output row remap (sub-pixel phases of a transposed conv): when out_row_div > 0,
      * row i of C is stored at row (i / div) * hi + (i % div) * lo + off of out / out2. */
     int out_row_div, out_row_hi, out_row_lo, out_row_off;
 } vp_gemm_args;
 
 int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);
+/* out[i] (+)= sum_z slab[z*stride + i], i < n: the deterministic reduction of the split-K slabs
+ * (weight gradients; replaces autograd's dW accumulation of nn.Linear / conv layers). */
+int vp_splitk_reduce(const float* slab, int nsplit, long stride, size_t n, float* out, int accumulate,
+                     vp_stream_t stream);
 
 /* dtype tags for the layout/cast helpers */
 enum { VP_F32 = 0, VP_BF16 = 1 };

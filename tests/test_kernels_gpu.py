@@ -87,10 +87,17 @@ def test_gemm_epilogues(dev):
     torch.testing.assert_close(out.float(), acc * a.grad, rtol=2e-2, atol=2e-2)
     run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, aux=aux, ldaux=N, epilogue=_lib.VP_EPI_DRELU))
     torch.testing.assert_close(out.float(), (acc * (aux.float() > 0)).bfloat16().float(), rtol=1e-2, atol=1e-2)
-    # ATOMIC split-K accumulate on top of existing values (integer data: exact)
+    # split-K slabs + reduce, accumulating on top of existing values (integer data: exact);
+    # 5 slices over 8 K steps leaves the last slice empty (it must still write zeros)
     Xi, Yi = ints((M, 512), dev, seed=10).bfloat16(), ints((N, 512), dev, seed=11).bfloat16()
     o32.fill_(1.0)
-    run(lambda p: p.gemm(Xi, Yi, o32, M, N, 512, ldx=512, ldy=512, ldo=N, epilogue=_lib.VP_EPI_ATOMIC_F32, split_k=4))
+    slab = torch.full((5 * M * N,), float('nan'), device=dev)
+
+    def splitk(p):
+        p.gemm(Xi, Yi, slab, M, N, 512, ldx=512, ldy=512, ldo=N, epilogue=_lib.VP_EPI_SPLITK_F32, split_k=5,
+               split_stride=M * N)
+        p._add('vp_splitk_reduce', slab.data_ptr(), 5, M * N, M * N, o32.data_ptr(), 1)
+    run(splitk)
     assert torch.equal(o32, Xi.float() @ Yi.float().t() + 1.0)
     # output row remap (sub-pixel phase placement): row i -> (i / W) * 4W + (i % W) * 2 + off
     W = 12
@@ -244,8 +251,8 @@ def test_deconv_as_subpixel_gemms(dev):
         p.strided_cast(wt, wd, (Ci, 16, Co, 1), (Co * 16, 1, 16, 0))
         p.deconv_out_gather16(dcl, G, B, H, W, Co)
         p.gemm(G, wd, dx, B * H * W, Ci, 16 * Co, ldx=16 * Co, ldy=16 * Co, ldo=Ci, epilogue=_lib.VP_EPI_F32)
-        p.gemm(xcl, G, dwd, Ci, 16 * Co, B * H * W, ldx=Ci, ldy=16 * Co, ldo=16 * Co, x_kmajor=True, y_kmajor=True,
-               epilogue=_lib.VP_EPI_ATOMIC_F32, split_k=3)
+        p.wgrad(xcl, G, dwd, Ci, 16 * Co, B * H * W, ldx=Ci, ldy=16 * Co, split_k=3,
+                slab=torch.empty(3 * Ci * 16 * Co, device=dev))
     run(bwd)
     assert torch.equal(dx.view(B, H, W, Ci).permute(0, 3, 1, 2), xr.grad)
     assert torch.equal(dwd.view(Ci, 16, Co).permute(0, 2, 1).reshape(Ci, Co, 4, 4), wr.grad)

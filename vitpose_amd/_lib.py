@@ -5,13 +5,15 @@ export a symbol, importing this module's `lib()` raises.
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  (first: the library must bind to the HIP runtime torch has loaded)
 from ctypes import POINTER, Structure, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
 
 VP_EPI_BF16, VP_EPI_GELU, VP_EPI_RESID_F32, VP_EPI_DGELU = 0, 1, 2, 3
-VP_EPI_ATOMIC_F32, VP_EPI_F32, VP_EPI_SCALE_RELU, VP_EPI_DRELU = 4, 5, 6, 7
+VP_EPI_SPLITK_F32, VP_EPI_F32, VP_EPI_SCALE_RELU, VP_EPI_DRELU = 4, 5, 6, 7
 VP_F32, VP_BF16 = 0, 1
 
 
@@ -27,7 +29,7 @@ class GemmArgs(Structure):
         ('rowscale', c_void_p), ('rows_per_scale', c_int),
         ('aux', c_void_p), ('ldaux', c_int),
         ('pos', c_void_p), ('pos_rows', c_int),
-        ('split_k', c_int),
+        ('split_k', c_int), ('split_stride', c_long),
         ('out_row_div', c_int), ('out_row_hi', c_int), ('out_row_lo', c_int), ('out_row_off', c_int),
     ]
 
@@ -36,6 +38,7 @@ P = c_void_p
 # name -> argtypes (the trailing stream argument included); every function returns int
 SIGNATURES = {
     'vp_gemm_bf16': [POINTER(GemmArgs), P],
+    'vp_splitk_reduce': [P, c_int, c_long, c_size_t, P, c_int, P],
     'vp_layernorm_fwd': [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P],
     'vp_attention_fwd': [P, P, P, c_int, c_int, c_int, c_int, c_float, P],

@@ -129,6 +129,16 @@ __global__ __launch_bounds__(256) void deconv_out_gather16_kernel(const bf16* __
     }
 }
 
+// ---- out[i] (+)= sum over the split-K slabs ----
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int nsplit, long stride,
+                                                            size_t n4, float* __restrict__ out, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(out + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * stride + i * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = s;
+    }
+}
+
 inline int grid_for(size_t work_items) {
     size_t g = (work_items + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g ? g : 1));
@@ -172,6 +182,14 @@ extern "C" int vp_colsum_bf16(const void* a, float* out, int M, int N, int lda, 
     if (gy > 512) gy = 512;
     const int rpb = (M + gy - 1) / gy;
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)a, out, M, N, lda, rpb);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_splitk_reduce(const float* slab, int nsplit, long stride, size_t n, float* out, int accumulate,
+                                hipStream_t stream) {
+    VP_CHECK_ARG(slab && out && nsplit > 0 && n > 0 && n % 4 == 0 && stride % 4 == 0 && (size_t)stride >= n);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, slab, nsplit, stride, n / 4,
+                       out, accumulate);
     VP_LAUNCH_RET();
 }
 

@@ -8,7 +8,7 @@
 // one kernel body and no transposed copies:
 //   forward  y = x W^T   : X = x  [M][K] k-contig, Y = W  [N][K] k-contig
 //   dgrad    dx = dy W    : X = dy [M][N] k-contig, Y = W  [N][K] k-major
-//   wgrad    dW = dy^T x  : X = dy [M][N] k-major,  Y = x  [M][K] k-major  (split-K + f32 atomics)
+//   wgrad    dW = dy^T x  : X = dy [M][N] k-major,  Y = x  [M][K] k-major  (split-K into f32 slabs)
 //
 // Tiling: 128x128x64 per 256-thread workgroup, 2x2 waves of 64x64, each wave 4x4
 // v_mfma_f32_16x16x32_bf16 tiles.  Operands are staged global -> registers -> LDS
@@ -106,58 +106,106 @@ struct Epi {
     const float* pos; int pos_rows;
     const float* colscale;
     int row_div, row_hi, row_lo, row_off;  // out row = (i / div) * hi + (i % div) * lo + off when div > 0
+    long split_stride;                     // elements between the K-slice slabs of VP_EPI_SPLITK_F32
 };
 
+// Epilogue of one wave's 64x64 sub-tile.  All per-column (bias / colscale) and per-row
+// (DropPath scale, residual / position row pointer, remapped output row) operands are fetched
+// before the 4x4 tile loop, and loads inside the loop use clamped in-bounds addresses, so the
+// loop body is branch-free apart from the predicated store and its loads can be batched.
 template <int EPI>
-__device__ __forceinline__ void epilogue_store(const Epi& e, int row, int col, f32x4 v) {
-    // (row, col..col+3) of C; caller guarantees row < M and col + 3 < N
-    const size_t orow = e.row_div > 0 ? (size_t)(row / e.row_div) * e.row_hi + (row % e.row_div) * e.row_lo + e.row_off
-                                      : (size_t)row;
-    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
-        if (e.colscale) {
-            const f32x4 s = *reinterpret_cast<const f32x4*>(e.colscale + col);
-            v *= s;
-        }
+__device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[4][4], int i0, int j0, int wm, int wn,
+                                             int lane, int M, int N) {
+    const int g = lane >> 4, li = lane & 15;
+    int col[4];
+    bool cok[4];
+    f32x4 bias[4], cs[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int c = j0 + wn * 64 + b * 16 + g * 4;
+        cok[b] = c + 3 < N;
+        col[b] = cok[b] ? c : N - 4;
+        bias[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs[b] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    if constexpr (EPI != VP_EPI_SPLITK_F32 && EPI != VP_EPI_DGELU && EPI != VP_EPI_DRELU) {
         if (e.bias) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + col);
-            v += b;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
         }
-        if constexpr (EPI == VP_EPI_GELU) {
-            if (e.out2)
-                *reinterpret_cast<bf16x4*>((bf16*)e.out2 + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
+    }
+    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU) {
+        if (e.colscale) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            for (int b = 0; b < 4; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
         }
-        if constexpr (EPI == VP_EPI_SCALE_RELU) {
+    }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    for (int a = 0; a < 4; ++a) {
+        const int row_raw = i0 + wm * 64 + a * 16 + li;
+        const bool rok = row_raw < M;
+        const int row = rok ? row_raw : M - 1;
+        const size_t orow = e.row_div > 0
+                                ? (size_t)(row / e.row_div) * e.row_hi + (row % e.row_div) * e.row_lo + e.row_off
+                                : (size_t)row;
+        if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
+            bf16* o = (bf16*)e.out + orow * e.ldo;
+            bf16* o2 = EPI == VP_EPI_GELU && e.out2 ? (bf16*)e.out2 + orow * e.ldo : nullptr;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                f32x4 v = acc[a][b] * cs[b] + bias[b];
+                const bool ok = rok && cok[b];
+                if constexpr (EPI == VP_EPI_GELU) {
+                    if (o2 && ok) *reinterpret_cast<bf16x4*>(o2 + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                if constexpr (EPI == VP_EPI_SCALE_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (ok) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        } else if constexpr (EPI == VP_EPI_RESID_F32) {
+            // out = addend + rowscale[row / rows_per_scale] * (acc + bias), addend = resid row or pos row
+            const float rs = e.rowscale ? e.rowscale[row / e.rows_per_scale] : 1.f;
+            const float* add = e.resid ? e.resid + (size_t)row * e.ldo
+                                       : (e.pos ? e.pos + (size_t)(row % e.pos_rows) * e.ldo : nullptr);
+            float* o = (float*)e.out + orow * e.ldo;
+            f32x4 ad[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                ad[b] = add ? *reinterpret_cast<const f32x4*>(add + col[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 v = ad[b] + (acc[a][b] + bias[b]) * rs;
+                if (rok && cok[b]) *reinterpret_cast<f32x4*>(o + col[b]) = v;
+            }
+        } else if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
+            const bf16* ax = (const bf16*)e.aux + (size_t)row * e.ldaux;
+            bf16* o = (bf16*)e.out + orow * e.ldo;
+            bf16x4 u[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) u[b] = *reinterpret_cast<const bf16x4*>(ax + col[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                f32x4 v = acc[a][b];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (EPI == VP_EPI_DGELU) v[r] *= gelu_erf_grad((float)u[b][r]);
+                    else v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
+                }
+                if (rok && cok[b]) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        } else {  // VP_EPI_F32, VP_EPI_SPLITK_F32 (slice blockIdx.y of the partial-sum slab)
+            float* o = (float*)e.out + orow * e.ldo;
+            if constexpr (EPI == VP_EPI_SPLITK_F32) o += (size_t)blockIdx.y * e.split_stride;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 v = acc[a][b] + bias[b];
+                if (rok && cok[b]) *reinterpret_cast<f32x4*>(o + col[b]) = v;
+            }
         }
-        *reinterpret_cast<bf16x4*>((bf16*)e.out + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (EPI == VP_EPI_RESID_F32) {
-        // out = resid + rowscale[row / rows_per_scale] * (acc + bias) (+ pos[row % pos_rows])
-        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + col);
-        if (e.rowscale) v *= e.rowscale[row / e.rows_per_scale];
-        if (e.resid) v += *reinterpret_cast<const f32x4*>(e.resid + (size_t)row * e.ldo + col);
-        if (e.pos) v += *reinterpret_cast<const f32x4*>(e.pos + (size_t)(row % e.pos_rows) * e.ldo + col);
-        *reinterpret_cast<f32x4*>((float*)e.out + orow * e.ldo + col) = v;
-    } else if constexpr (EPI == VP_EPI_DGELU) {
-        const bf16x4 u = *reinterpret_cast<const bf16x4*>((const bf16*)e.aux + (size_t)row * e.ldaux + col);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
-        *reinterpret_cast<bf16x4*>((bf16*)e.out + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (EPI == VP_EPI_ATOMIC_F32) {
-        float* o = (float*)e.out + orow * e.ldo + col;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(o + r, v[r]);
-    } else if constexpr (EPI == VP_EPI_F32) {
-        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + col);
-        *reinterpret_cast<f32x4*>((float*)e.out + orow * e.ldo + col) = v;
-    } else if constexpr (EPI == VP_EPI_DRELU) {
-        // out = acc * (aux > 0)   (aux = the ReLU's bf16 output)
-        const bf16x4 a = *reinterpret_cast<const bf16x4*>((const bf16*)e.aux + (size_t)row * e.ldaux + col);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (float)a[r] > 0.f ? v[r] : 0.f;
-        *reinterpret_cast<bf16x4*>((bf16*)e.out + orow * e.ldo + col) = pack4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -175,7 +223,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
     const int nk_all = K / BK;
     const int kt0 = blockIdx.y * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
-    if (kt0 >= kt1) return;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -183,53 +230,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 xr[4], yr[4];
-    load_tile<XKMAJ>(X, i0, kt0 * BK, tid, xr);
-    load_tile<YKMAJ>(Y, j0, kt0 * BK, tid, yr);
-    store_tile<XKMAJ>(lds[0][0], tid, xr);
-    store_tile<YKMAJ>(lds[0][1], tid, yr);
-    __syncthreads();
-
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) {
-            load_tile<XKMAJ>(X, i0, (kt + 1) * BK, tid, xr);
-            load_tile<YKMAJ>(Y, j0, (kt + 1) * BK, tid, yr);
-        }
-        const char* lx = lds[cur][0];
-        const char* ly = lds[cur][1];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 xf[4], yf[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) xf[a] = read_frag<XKMAJ>(lx, wm * 64 + a * 16, s, lane);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) yf[b] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
-        }
-        if (more) {
-            store_tile<XKMAJ>(lds[cur ^ 1][0], tid, xr);
-            store_tile<YKMAJ>(lds[cur ^ 1][1], tid, yr);
-        }
+    if (kt0 < kt1) {  // an empty K slice still writes its (zero) partial tile
+        uint4 xr[4], yr[4];
+        load_tile<XKMAJ>(X, i0, kt0 * BK, tid, xr);
+        load_tile<YKMAJ>(Y, j0, kt0 * BK, tid, yr);
+        store_tile<XKMAJ>(lds[0][0], tid, xr);
+        store_tile<YKMAJ>(lds[0][1], tid, yr);
         __syncthreads();
-    }
 
-    const int g = lane >> 4, li = lane & 15;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            const bool more = kt + 1 < kt1;
+            // issue the next tile's global loads, run this tile's MFMAs under their latency,
+            // and only then park the registers in the other LDS buffer (the scheduling
+            // barriers keep hipcc from hoisting the wait + LDS writes above the MFMAs)
+            if (more) {
+                load_tile<XKMAJ>(X, i0, (kt + 1) * BK, tid, xr);
+                load_tile<YKMAJ>(Y, j0, (kt + 1) * BK, tid, yr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const char* lx = lds[cur][0];
+            const char* ly = lds[cur][1];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int row = i0 + wm * 64 + a * 16 + li;
-        if (row >= M) continue;
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 xf[4], yf[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int col = j0 + wn * 64 + b * 16 + g * 4;
-            if (col + 3 < N) epilogue_store<EPI>(e, row, col, acc[a][b]);
+                for (int a = 0; a < 4; ++a) xf[a] = read_frag<XKMAJ>(lx, wm * 64 + a * 16, s, lane);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) yf[b] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                store_tile<XKMAJ>(lds[cur ^ 1][0], tid, xr);
+                store_tile<YKMAJ>(lds[cur ^ 1][1], tid, yr);
+            }
+            __syncthreads();
         }
     }
+    run_epilogue<EPI>(e, acc, i0, j0, wm, wn, lane, M, N);
 }
 
 template <bool XK, bool YK>
@@ -237,13 +280,13 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
     Operand X{(const bf16*)a->x, a->ldx, a->M}, Y{(const bf16*)a->y, a->ldy, a->N};
     Epi e{a->epilogue, a->out, a->ldo, a->out2, a->bias, a->resid, a->rowscale, a->rows_per_scale,
           a->aux, a->ldaux, a->pos, a->pos_rows, a->colscale,
-          a->out_row_div, a->out_row_hi, a->out_row_lo, a->out_row_off};
+          a->out_row_div, a->out_row_hi, a->out_row_lo, a->out_row_off, a->split_stride};
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
     const int nk = a->K / BK;
     int split = a->split_k > 0 ? a->split_k : 1;
     if (split > nk) split = nk;
-    if (a->epilogue != VP_EPI_ATOMIC_F32) split = 1;
+    if (a->epilogue != VP_EPI_SPLITK_F32) split = 1;
     const int ksplit_tiles = (nk + split - 1) / split;
     dim3 grid(ntiles, split);
 #define VP_GEMM_CASE(EPI)                                                                         \
@@ -256,7 +299,7 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
         VP_GEMM_CASE(VP_EPI_GELU)
         VP_GEMM_CASE(VP_EPI_RESID_F32)
         VP_GEMM_CASE(VP_EPI_DGELU)
-        VP_GEMM_CASE(VP_EPI_ATOMIC_F32)
+        VP_GEMM_CASE(VP_EPI_SPLITK_F32)
         VP_GEMM_CASE(VP_EPI_F32)
         VP_GEMM_CASE(VP_EPI_SCALE_RELU)
         VP_GEMM_CASE(VP_EPI_DRELU)

@@ -95,10 +95,21 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
-def _split_k(M, N, K, target_blocks=768):
+SPLITK_TARGET_BLOCKS = 512  # ~2 workgroups per CU
+
+
+def _split_k(M, N, K, target_blocks=None):
+    """K slices of a weight-gradient GEMM so that tiles * slices covers the chip."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nk = K // 64
-    return max(1, min(nk, (target_blocks + tiles - 1) // tiles))
+    return max(1, min(nk, (target_blocks or SPLITK_TARGET_BLOCKS) // tiles))
+
+
+def _slab_elems(out_elems, K, target_blocks=None):
+    """Upper bound of split_k * out_elems over outputs of at most `out_elems` elements."""
+    tb = target_blocks or SPLITK_TARGET_BLOCKS
+    # split <= tb / tiles and tiles >= out_elems / 128^2  =>  split * out_elems <= tb * 128^2 (+ one slab)
+    return int(tb * 128 * 128 + out_elems)
 
 
 # =====================================================================================
@@ -252,7 +263,7 @@ class VitRunner:
                         dp: Optional[torch.Tensor] = None, after_block=None):
         """dfeat = bf16 [B*T][E] gradient wrt the final feature.  Accumulates into store.grad."""
         E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
-        ATOM = _lib.VP_EPI_ATOMIC_F32
+        slab = ws.f32('splitk_slab', _slab_elems(max(E * Hd, 3 * E * E, E * self.Kpe), M))
 
         def dp_scale(i, j):
             if dp is not None and i >= 0 and self.dp_rates[i] > 0:
@@ -284,12 +295,12 @@ class VitRunner:
             plan.gemm(dxb, self.h(b + 'mlp.fc2.weight'), du, M, Hd, E, ldx=E, ldy=Hd, ldo=Hd, y_kmajor=True,
                       epilogue=_lib.VP_EPI_DGELU, aux=g['u' + s], ldaux=Hd)
             # dW2 [E][Hd] += dxb^T h
-            plan.gemm(dxb, g['h' + s], self.g(b + 'mlp.fc2.weight'), E, Hd, M, ldx=E, ldy=Hd, ldo=Hd,
-                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(E, Hd, M))
+            plan.wgrad(dxb, g['h' + s], self.g(b + 'mlp.fc2.weight'), E, Hd, M, ldx=E, ldy=Hd,
+                       split_k=_split_k(E, Hd, M), slab=slab)
             # dxn2 = du W1 ; dW1 [Hd][E] += du^T xn2 ; db1 = colsum(du)
             plan.gemm(du, self.h(b + 'mlp.fc1.weight'), dxn, M, E, Hd, ldx=Hd, ldy=E, ldo=E, y_kmajor=True)
-            plan.gemm(du, g['xn2' + s], self.g(b + 'mlp.fc1.weight'), Hd, E, M, ldx=Hd, ldy=E, ldo=E,
-                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(Hd, E, M))
+            plan.wgrad(du, g['xn2' + s], self.g(b + 'mlp.fc1.weight'), Hd, E, M, ldx=Hd, ldy=E,
+                       split_k=_split_k(Hd, E, M), slab=slab)
             plan.colsum(du, self.g(b + 'mlp.fc1.bias'), M, Hd, Hd)
             # LN2 backward, residual add, scaled bf16 copy for the attention branch, proj bias grad
             plan.layernorm_bwd(dxn, g['x_mid' + s], g['mean2' + s], g['rstd2' + s], self.w(b + 'norm2.weight'),
@@ -298,13 +309,13 @@ class VitRunner:
             dx, other = other, dx
             # ---- attention branch
             plan.gemm(dxb, self.h(b + 'attn.proj.weight'), dao, M, E, E, ldx=E, ldy=E, ldo=E, y_kmajor=True)
-            plan.gemm(dxb, g['ao' + s], self.g(b + 'attn.proj.weight'), E, E, M, ldx=E, ldy=E, ldo=E,
-                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(E, E, M))
+            plan.wgrad(dxb, g['ao' + s], self.g(b + 'attn.proj.weight'), E, E, M, ldx=E, ldy=E,
+                       split_k=_split_k(E, E, M), slab=slab)
             plan.attention_bwd(g['qkv' + s], g['ao' + s], dao, g['lse' + s], dqkv, B, self.heads, self.d, T,
                                self.scale)
             plan.gemm(dqkv, self.h(b + 'attn.qkv.weight'), dxn, M, E, 3 * E, ldx=3 * E, ldy=E, ldo=E, y_kmajor=True)
-            plan.gemm(dqkv, g['xn1' + s], self.g(b + 'attn.qkv.weight'), 3 * E, E, M, ldx=3 * E, ldy=E, ldo=E,
-                      x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(3 * E, E, M))
+            plan.wgrad(dqkv, g['xn1' + s], self.g(b + 'attn.qkv.weight'), 3 * E, E, M, ldx=3 * E, ldy=E,
+                       split_k=_split_k(3 * E, E, M), slab=slab)
             if self.has(b + 'attn.qkv.bias'):
                 plan.colsum(dqkv, self.g(b + 'attn.qkv.bias'), M, 3 * E, 3 * E)
             # LN1 backward: bf16 copy is scaled for the previous block's MLP branch (or unscaled for
@@ -318,8 +329,8 @@ class VitRunner:
                 # every gradient of blocks >= i is final here except fc2.bias of block i-1
                 after_block(plan, i)
         # ---- patch embedding + position embedding
-        plan.gemm(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
-                  ldo=self.Kpe, x_kmajor=True, y_kmajor=True, epilogue=ATOM, split_k=_split_k(E, self.Kpe, M))
+        plan.wgrad(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
+                   split_k=_split_k(E, self.Kpe, M), slab=slab)
         plan.batch_sum(dx, self.dpos, B, T * E)
         gp = self.g('pos_embed')[0]
 

@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from .engine import ParamStore, Workspace, _split_k
+from .engine import ParamStore, Workspace, _slab_elems, _split_k
 from .plan import Plan
 
 KPAD = 64  # the K=17 heat-map channels are padded to one 64-wide MFMA K step / 4 column tiles
@@ -153,16 +153,15 @@ class HeadRunner:
 
     # -- backward: returns the bf16 gradient wrt `feat` --
     def record_backward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat: torch.Tensor, B: int):
-        ATOM = _lib.VP_EPI_ATOMIC_F32
         H, W = self.out_hw
         Mh = B * H * W
         cl = self.chans[-1]
         a_last = ws.bufs[f'a.{self.nl - 1}'] if self.nl else feat
         # final 1x1 conv
-        plan.memset0(self.dwf)
+        slab = ws.f32('splitk_slab_head', _slab_elems(max(self.chans[l] * 16 * self.chans[l + 1]
+                                                          for l in range(self.nl)) if self.nl else KPAD * cl, Mh))
         plan.memset0(self.dbf)
-        plan.gemm(dheat, a_last, self.dwf, KPAD, cl, Mh, ldx=KPAD, ldy=cl, ldo=cl, x_kmajor=True, y_kmajor=True,
-                  epilogue=ATOM, split_k=_split_k(KPAD, cl, Mh, 512))
+        plan.wgrad(dheat, a_last, self.dwf, KPAD, cl, Mh, ldx=KPAD, ldy=cl, split_k=_split_k(KPAD, cl, Mh), slab=slab)
         plan.colsum(dheat, self.dbf, Mh, KPAD, KPAD)
         gW, gb, dwf, dbf, K = self.g('final_layer.weight'), self.g('final_layer.bias'), self.dwf, self.dbf, self.K
 
@@ -188,9 +187,8 @@ class HeadRunner:
             plan.deconv_out_gather16(dz, G, B, Hi, Wi, co)
             a_in = ws.bufs[f'a.{l - 1}'] if l > 0 else feat
             # dWd [ci][16co] = a_in^T G
-            plan.memset0(self.dwd[l])
-            plan.gemm(a_in, G, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=16 * co, ldo=16 * co, x_kmajor=True,
-                      y_kmajor=True, epilogue=ATOM, split_k=_split_k(ci, 16 * co, Min, 1024))
+            plan.wgrad(a_in, G, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=16 * co,
+                       split_k=_split_k(ci, 16 * co, Min), slab=slab)
             gw, dwd = self.g(f'deconv_layers.{3 * l}.weight'), self.dwd[l]
 
             def wgrad(gw=gw, dwd=dwd, ci=ci, co=co):
