@@ -46,7 +46,8 @@ const char* vp_build_arch(void);
 enum {
     VP_EPI_BF16 = 0,       /* out(bf16) = acc*colscale + bias                                   */
     VP_EPI_GELU = 1,       /* out2(bf16, optional) = u = acc + bias; out(bf16) = gelu_erf(u)    */
-    VP_EPI_RESID_F32 = 2,  /* out(f32) = resid + rowscale[i/rows_per_scale]*(acc+bias) + pos[i%pos_rows] */
+    VP_EPI_RESID_F32 = 2,  /* out(f32) = addend + rowscale[i/rows_per_scale]*(acc+bias); addend = resid row i,
+                              else pos row i%pos_rows (resid wins when both are given), else 0 */
     VP_EPI_DGELU = 3,      /* out(bf16) = acc * gelu_erf'(aux(bf16))                            */
     VP_EPI_SPLITK_F32 = 4, /* K slice z of split_k writes its partial sums to out + z*split_stride (f32) */
     VP_EPI_F32 = 5,        /* out(f32) = acc + bias                                             */

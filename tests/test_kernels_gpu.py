@@ -76,9 +76,13 @@ def test_gemm_epilogues(dev):
     rs = torch.tensor([0.0, 1.0 / 0.7], device=dev)
     o32 = torch.empty(M, N, device=dev)
     run(lambda p: p.gemm(X, Y, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, resid=resid, rowscale=rs,
-                         rows_per_scale=T, pos=pos, pos_rows=T, epilogue=_lib.VP_EPI_RESID_F32))
-    ref = resid + rs.repeat_interleave(T)[:, None] * (acc + bias) + pos.repeat(2, 1)
+                         rows_per_scale=T, epilogue=_lib.VP_EPI_RESID_F32))
+    ref = resid + rs.repeat_interleave(T)[:, None] * (acc + bias)
     torch.testing.assert_close(o32, ref, rtol=1e-4, atol=1e-4)
+    # the addend is the residual row OR the position row (row % pos_rows), never both
+    run(lambda p: p.gemm(X, Y, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, pos=pos, pos_rows=T,
+                         epilogue=_lib.VP_EPI_RESID_F32))
+    torch.testing.assert_close(o32, acc + bias + pos.repeat(2, 1), rtol=1e-4, atol=1e-4)
     # DGELU / DRELU
     aux = rnd((M, N), dev, 9).bfloat16()
     run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, aux=aux, ldaux=N, epilogue=_lib.VP_EPI_DGELU))

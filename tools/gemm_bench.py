@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of vp_gemm_bf16 on the ViTPose-B GEMM shapes (64 images = 12288 tokens):
+forward (k-contig x k-contig), dgrad (k-contig x k-major), wgrad (k-major x k-major + split-K).
+Random operands (zero-filled data flatters MFMA clocks)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vitpose_amd import _lib  # noqa: E402
+from vitpose_amd.engine import _slab_elems, _split_k  # noqa: E402
+from vitpose_amd.plan import Plan  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--tokens', type=int, default=12288)
+    ap.add_argument('--embed', type=int, default=768)
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    M, E = args.tokens, args.embed
+    g = torch.Generator().manual_seed(0)
+
+    def rb(*s):
+        return (torch.rand(*s, generator=g) * 2 - 1).to(dev).bfloat16()
+    cases = []
+    for name, N, K in (('qkv', 3 * E, E), ('proj', E, E), ('fc1', 4 * E, E), ('fc2', E, 4 * E)):
+        x, w = rb(M, K), rb(N, K)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        cases.append((f'fwd_{name}   M{M} N{N} K{K}', 2.0 * M * N * K,
+                      lambda p, x=x, w=w, out=out, N=N, K=K: p.gemm(x, w, out, M, N, K, ldx=K, ldy=K, ldo=N)))
+        dy = rb(M, N)
+        dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+        cases.append((f'dgrad_{name} M{M} N{K} K{N}', 2.0 * M * N * K,
+                      lambda p, dy=dy, w=w, dx=dx, N=N, K=K: p.gemm(dy, w, dx, M, K, N, ldx=N, ldy=K, ldo=K,
+                                                                    y_kmajor=True)))
+        dw = torch.empty(N, K, device=dev)
+        slab = torch.empty(_slab_elems(N * K, M), device=dev)
+        sk = _split_k(N, K, M)
+        cases.append((f'wgrad_{name} M{N} N{K} K{M} split{sk}', 2.0 * M * N * K,
+                      lambda p, dy=dy, x=x, dw=dw, slab=slab, N=N, K=K, sk=sk: p.wgrad(
+                          dy, x, dw, N, K, M, ldx=N, ldy=K, split_k=sk, slab=slab)))
+    for name, flops, build in cases:
+        if args.only and args.only not in name:
+            continue
+        p = Plan()
+        build(p)
+        for _ in range(3):
+            p.run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            p.run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.reps
+        print(f'{name:44s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -36,46 +36,57 @@ struct Operand {
     int rows;  // extent of the non-reduction index
 };
 
-// ---- global -> registers (one 128x64 tile = 4 x 16 B per thread) ----
+// One thread's share of a 128x64 operand tile: 4 x 16 B.  Kept as four named members and passed
+// by value so the staging registers stay in VGPRs (an indexed local array handed around by
+// reference gets demoted to scratch / LDS by hipcc, which serialises the whole pipeline).
+struct Stage {
+    uint4 a, b, c, d;
+};
+
+// ---- global -> registers ----
 template <bool KMAJ>
-__device__ __forceinline__ void load_tile(const Operand& op, int r0, int k0, int tid, uint4 (&v)[4]) {
+__device__ __forceinline__ Stage load_tile(const Operand& op, int r0, int k0, int tid) {
+    Stage s;
     if constexpr (!KMAJ) {
         const int c = tid & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        const bf16* base = op.p + k0 + c * 8;
+        auto ld = [&](int i) {
             int r = r0 + (tid >> 3) + 32 * i;
             r = r < op.rows ? r : op.rows - 1;  // clamped rows only feed masked outputs
-            v[i] = *reinterpret_cast<const uint4*>(op.p + (size_t)r * op.ld + k0 + c * 8);
-        }
+            return *reinterpret_cast<const uint4*>(base + (size_t)r * op.ld);
+        };
+        s.a = ld(0); s.b = ld(1); s.c = ld(2); s.d = ld(3);
     } else {
         const int c = tid & 15;
         int col = r0 + c * 8;
         col = col <= op.rows - 8 ? col : op.rows - 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        const bf16* base = op.p + col;
+        auto ld = [&](int i) {
             const int kr = (tid >> 4) + 16 * i;
-            v[i] = *reinterpret_cast<const uint4*>(op.p + (size_t)(k0 + kr) * op.ld + col);
-        }
+            return *reinterpret_cast<const uint4*>(base + (size_t)(k0 + kr) * op.ld);
+        };
+        s.a = ld(0); s.b = ld(1); s.c = ld(2); s.d = ld(3);
     }
+    return s;
 }
 
 // ---- registers -> LDS (swizzled) ----
 template <bool KMAJ>
-__device__ __forceinline__ void store_tile(char* lds, int tid, const uint4 (&v)[4]) {
+__device__ __forceinline__ void store_tile(char* lds, int tid, const Stage& s) {
     if constexpr (!KMAJ) {
         const int c = tid & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        auto st = [&](int i, const uint4& v) {
             const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ (r & 7)) << 4)) = v[i];
-        }
+            *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ (r & 7)) << 4)) = v;
+        };
+        st(0, s.a); st(1, s.b); st(2, s.c); st(3, s.d);
     } else {
         const int c = tid & 15;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        auto st = [&](int i, const uint4& v) {
             const int kr = (tid >> 4) + 16 * i;
-            *reinterpret_cast<uint4*>(lds + kr * 256 + (((c >> 1) ^ kmaj_key(kr)) << 5) + ((c & 1) << 4)) = v[i];
-        }
+            *reinterpret_cast<uint4*>(lds + kr * 256 + (((c >> 1) ^ kmaj_key(kr)) << 5) + ((c & 1) << 4)) = v;
+        };
+        st(0, s.a); st(1, s.b); st(2, s.c); st(3, s.d);
     }
 }
 
@@ -218,8 +229,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
 
     // tile order: the N tiles of one 128-row panel are consecutive, and each XCD
     // (blocks congruent mod 8) gets a contiguous chunk of that order
+    // ... and inside it tiles are walked in groups of 8 row panels, column by column, so the ~64
+    // workgroups an XCD runs at once cover an 8x8 patch of tiles: 16 operand panels shared
+    // through that XCD's 4 MiB L2 instead of a few row panels against the whole weight matrix
     const int t = xcd_remap(blockIdx.x, ntiles);
-    const int i0 = (t / tiles_n) * BM, j0 = (t % tiles_n) * BN;
+    const int tiles_m = ntiles / tiles_n;
+    const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
+    const int gm = min(tiles_m - gid * 8, 8);
+    const int i0 = (gid * 8 + tin % gm) * BM, j0 = (tin / gm) * BN;
     const int nk_all = K / BK;
     const int kt0 = blockIdx.y * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
@@ -231,23 +248,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (kt0 < kt1) {  // an empty K slice still writes its (zero) partial tile
-        uint4 xr[4], yr[4];
-        load_tile<XKMAJ>(X, i0, kt0 * BK, tid, xr);
-        load_tile<YKMAJ>(Y, j0, kt0 * BK, tid, yr);
-        store_tile<XKMAJ>(lds[0][0], tid, xr);
-        store_tile<YKMAJ>(lds[0][1], tid, yr);
+        Stage xs = load_tile<XKMAJ>(X, i0, kt0 * BK, tid);
+        Stage ys = load_tile<YKMAJ>(Y, j0, kt0 * BK, tid);
+        store_tile<XKMAJ>(lds[0][0], tid, xs);
+        store_tile<YKMAJ>(lds[0][1], tid, ys);
         __syncthreads();
 
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
-            const bool more = kt + 1 < kt1;
-            // issue the next tile's global loads, run this tile's MFMAs under their latency,
-            // and only then park the registers in the other LDS buffer (the scheduling
-            // barriers keep hipcc from hoisting the wait + LDS writes above the MFMAs)
-            if (more) {
-                load_tile<XKMAJ>(X, i0, (kt + 1) * BK, tid, xr);
-                load_tile<YKMAJ>(Y, j0, (kt + 1) * BK, tid, yr);
-            }
+            // issue the next tile's global loads (the last step re-loads its own tile: branch-free),
+            // run this tile's MFMAs under their latency, and only then park the registers in the
+            // other LDS buffer (the scheduling barriers keep hipcc from hoisting the wait + LDS
+            // writes above the MFMAs)
+            const int kn = min(kt + 1, kt1 - 1) * BK;
+            xs = load_tile<XKMAJ>(X, i0, kn, tid);
+            ys = load_tile<YKMAJ>(Y, j0, kn, tid);
             __builtin_amdgcn_sched_barrier(0);
             const char* lx = lds[cur][0];
             const char* ly = lds[cur][1];
@@ -265,10 +280,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                store_tile<XKMAJ>(lds[cur ^ 1][0], tid, xr);
-                store_tile<YKMAJ>(lds[cur ^ 1][1], tid, yr);
-            }
+            store_tile<XKMAJ>(lds[cur ^ 1][0], tid, xs);
+            store_tile<YKMAJ>(lds[cur ^ 1][1], tid, ys);
             __syncthreads();
         }
     }
