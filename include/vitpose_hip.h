@@ -98,7 +98,10 @@ int vp_layernorm_fwd(const float* x, const float* gamma, const float* beta, void
 int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
                      const float* gamma, const float* dres, float* dx, void* dxb_bf16,
                      const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
-                     float* dcolsum, int M, int E, vp_stream_t stream);
+                     float* dcolsum, int M, int E, float* workspace, size_t workspace_floats,
+                     vp_stream_t stream);
+/* workspace: caller-owned scratch for the per-workgroup partial column sums, at least 3*E floats
+ * (3*E*512 floats lets the kernel use its full grid). */
 
 /* ------------------------------------------------------------- Attention --------
  * Attention.forward core, vit.py:102-111: softmax(q k^T * scale) v over all `tokens`

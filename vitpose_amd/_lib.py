@@ -10,7 +10,7 @@ import torch  # noqa: F401  (first: the library must bind to the HIP runtime tor
 from ctypes import POINTER, Structure, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
+LIB_PATH = os.environ.get('VITPOSE_HIP_LIB') or os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
 
 VP_EPI_BF16, VP_EPI_GELU, VP_EPI_RESID_F32, VP_EPI_DGELU = 0, 1, 2, 3
 VP_EPI_SPLITK_F32, VP_EPI_F32, VP_EPI_SCALE_RELU, VP_EPI_DRELU = 4, 5, 6, 7
@@ -40,7 +40,7 @@ SIGNATURES = {
     'vp_gemm_bf16': [POINTER(GemmArgs), P],
     'vp_splitk_reduce': [P, c_int, c_long, c_size_t, P, c_int, P],
     'vp_layernorm_fwd': [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
-    'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P],
+    'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, c_size_t, P],
     'vp_attention_fwd': [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     'vp_attention_bwd': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     'vp_patch_im2col': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

@@ -44,13 +44,28 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* lds_ptr) {
         (bf16x4 __attribute__((address_space(3)))*)(lds_ptr));
 }
 
+// erf(z) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution): one
+// v_rcp, one v_exp and a 5-term Horner chain instead of the ~40-instruction libm erff, which made
+// the GELU epilogues VALU-bound.  *e_out receives exp(-z^2) (shared with the Gaussian pdf).
+__device__ __forceinline__ float erf_as(float z, float* e_out) {
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    const float e = __expf(-az * az);
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    *e_out = e;
+    return copysignf(1.0f - p * t * e, z);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    float e;
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, &e));
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float e;
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, &e));
+    return cdf + x * 0.39894228040143267794f * e;  // exp(-(x/sqrt2)^2) = exp(-x^2/2)
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

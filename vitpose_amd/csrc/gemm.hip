@@ -11,9 +11,9 @@
 //   wgrad    dW = dy^T x  : X = dy [M][N] k-major,  Y = x  [M][K] k-major  (split-K into f32 slabs)
 //
 // Tiling: 128x128x64 per 256-thread workgroup, 2x2 waves of 64x64, each wave 4x4
-// v_mfma_f32_16x16x32_bf16 tiles.  Operands are staged global -> registers -> LDS
-// (issue the next tile's loads before the MFMAs of the current one, write them to
-// the other LDS buffer afterwards; one barrier per K step).  LDS images are
+// v_mfma_f32_16x16x32_bf16 tiles.  Operands go global -> LDS by LDS-DMA (the next tile's
+// copy is issued before the MFMAs of the current one into the other LDS buffer; one
+// barrier per K step).  LDS images are
 // XOR-swizzled: k-contiguous tiles are read with ds_read_b128 (conflict-free),
 // k-major tiles with ds_read_b64_tr_b16 (hardware transpose, conflict-free).
 // The MFMA A operand is the Y tile and the B operand the X tile, so a lane ends
@@ -36,57 +36,34 @@ struct Operand {
     int rows;  // extent of the non-reduction index
 };
 
-// One thread's share of a 128x64 operand tile: 4 x 16 B.  Kept as four named members and passed
-// by value so the staging registers stay in VGPRs (an indexed local array handed around by
-// reference gets demoted to scratch / LDS by hipcc, which serialises the whole pipeline).
-struct Stage {
-    uint4 a, b, c, d;
-};
-
-// ---- global -> registers ----
+// ---- global -> LDS, asynchronously (LDS-DMA: global_load_lds_dwordx4) ----
+// One wave instruction moves 64 x 16 B and lands them CONTIGUOUSLY in LDS (wave-uniform base +
+// lane * 16), so the XOR swizzle of the LDS image is applied on the per-lane global SOURCE
+// address instead: the lane whose data lands in 16-byte slot L of the tile fetches the chunk
+// that the swizzled image keeps there (the swizzles are involutions).  No staging VGPRs and no
+// ds_write instructions: the register->LDS write path (~79 B/clk/CU) was the bottleneck of the
+// register-staged version, not the MFMAs.
 template <bool KMAJ>
-__device__ __forceinline__ Stage load_tile(const Operand& op, int r0, int k0, int tid) {
-    Stage s;
-    if constexpr (!KMAJ) {
-        const int c = tid & 7;
-        const bf16* base = op.p + k0 + c * 8;
-        auto ld = [&](int i) {
-            int r = r0 + (tid >> 3) + 32 * i;
-            r = r < op.rows ? r : op.rows - 1;  // clamped rows only feed masked outputs
-            return *reinterpret_cast<const uint4*>(base + (size_t)r * op.ld);
-        };
-        s.a = ld(0); s.b = ld(1); s.c = ld(2); s.d = ld(3);
-    } else {
-        const int c = tid & 15;
-        int col = r0 + c * 8;
-        col = col <= op.rows - 8 ? col : op.rows - 8;
-        const bf16* base = op.p + col;
-        auto ld = [&](int i) {
-            const int kr = (tid >> 4) + 16 * i;
-            return *reinterpret_cast<const uint4*>(base + (size_t)(k0 + kr) * op.ld);
-        };
-        s.a = ld(0); s.b = ld(1); s.c = ld(2); s.d = ld(3);
-    }
-    return s;
-}
-
-// ---- registers -> LDS (swizzled) ----
-template <bool KMAJ>
-__device__ __forceinline__ void store_tile(char* lds, int tid, const Stage& s) {
-    if constexpr (!KMAJ) {
-        const int c = tid & 7;
-        auto st = [&](int i, const uint4& v) {
-            const int r = (tid >> 3) + 32 * i;
-            *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ (r & 7)) << 4)) = v;
-        };
-        st(0, s.a); st(1, s.b); st(2, s.c); st(3, s.d);
-    } else {
-        const int c = tid & 15;
-        auto st = [&](int i, const uint4& v) {
-            const int kr = (tid >> 4) + 16 * i;
-            *reinterpret_cast<uint4*>(lds + kr * 256 + (((c >> 1) ^ kmaj_key(kr)) << 5) + ((c & 1) << 4)) = v;
-        };
-        st(0, s.a); st(1, s.b); st(2, s.c); st(3, s.d);
+__device__ __forceinline__ void stage_tile(const Operand& op, int r0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int base = (i * 4 + wave) * 64;  // first 16-byte slot written by this wave instruction
+        const int L = base + lane;
+        const bf16* src;
+        if constexpr (!KMAJ) {
+            const int r = L >> 3, c = (L & 7) ^ (r & 7);
+            int row = r0 + r;
+            row = row < op.rows ? row : op.rows - 1;  // clamped rows only feed masked outputs
+            src = op.p + (size_t)row * op.ld + k0 + c * 8;
+        } else {
+            const int kr = L >> 4, s16 = L & 15;
+            const int unit = (s16 >> 1) ^ kmaj_key(kr);
+            int col = r0 + (unit * 2 + (s16 & 1)) * 8;
+            col = col <= op.rows - 8 ? col : op.rows - 8;
+            src = op.p + (size_t)(k0 + kr) * op.ld + col;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
     }
 }
 
@@ -248,22 +225,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (kt0 < kt1) {  // an empty K slice still writes its (zero) partial tile
-        Stage xs = load_tile<XKMAJ>(X, i0, kt0 * BK, tid);
-        Stage ys = load_tile<YKMAJ>(Y, j0, kt0 * BK, tid);
-        store_tile<XKMAJ>(lds[0][0], tid, xs);
-        store_tile<YKMAJ>(lds[0][1], tid, ys);
-        __syncthreads();
+        stage_tile<XKMAJ>(X, i0, kt0 * BK, lds[0][0], wave, lane);
+        stage_tile<YKMAJ>(Y, j0, kt0 * BK, lds[0][1], wave, lane);
+        __syncthreads();  // (waits for the LDS-DMA: hipcc drains vmcnt before the barrier)
 
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
-            // issue the next tile's global loads (the last step re-loads its own tile: branch-free),
-            // run this tile's MFMAs under their latency, and only then park the registers in the
-            // other LDS buffer (the scheduling barriers keep hipcc from hoisting the wait + LDS
-            // writes above the MFMAs)
-            const int kn = min(kt + 1, kt1 - 1) * BK;
-            xs = load_tile<XKMAJ>(X, i0, kn, tid);
-            ys = load_tile<YKMAJ>(Y, j0, kn, tid);
-            __builtin_amdgcn_sched_barrier(0);
+            // start the next tile's LDS-DMA into the other buffer (every wave finished reading it
+            // before the barrier that ended the previous step), then run this tile's MFMAs under it
+#ifndef VP_ABLATE_NOLOAD
+            if (kt + 1 < kt1) {
+                stage_tile<XKMAJ>(X, i0, (kt + 1) * BK, lds[cur ^ 1][0], wave, lane);
+                stage_tile<YKMAJ>(Y, j0, (kt + 1) * BK, lds[cur ^ 1][1], wave, lane);
+            }
+#endif
             const char* lx = lds[cur][0];
             const char* ly = lds[cur][1];
 #pragma unroll
@@ -276,12 +251,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < 4; ++b) {
+#ifndef VP_ABLATE_NOMFMA
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
+#else
+                        asm volatile("" ::"v"(yf[b]), "v"(xf[a]));
+#endif
+                    }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            store_tile<XKMAJ>(lds[cur ^ 1][0], tid, xs);
-            store_tile<YKMAJ>(lds[cur ^ 1][1], tid, ys);
             __syncthreads();
         }
     }

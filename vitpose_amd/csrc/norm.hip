@@ -63,14 +63,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Backward.  Each wave walks rows w, w + W, ... and keeps per-column partial sums of
 // dgamma / dbeta / (scaled dx column sum) in registers; one LDS reduction over the
-// block's 4 waves and one f32 atomic per column per block at the end.
+// block's 4 waves, then the block stores its partial sums for the finalize kernel.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx, bf16* __restrict__ dxb,
                                                      const float* __restrict__ rowscale, int rows_per_scale,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ dcolsum, int M, int E) {
+                                                     float* __restrict__ partial, int M, int E) {
     __shared__ float red[3][4][64 * 4 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = E >> 2;
@@ -142,10 +141,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             const float g_ = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
             const float b_ = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
             const float c_ = red[2][0][col] + red[2][1][col] + red[2][2][col] + red[2][3][col];
-            if (dgamma) atomicAdd(dgamma + e, g_);
-            if (dbeta) atomicAdd(dbeta + e, b_);
-            if (dcolsum) atomicAdd(dcolsum + e, c_);
+            // per-block partial sums [block][3][E]; hundreds of blocks adding atomically into the
+            // same E addresses would serialise at the memory side
+            float* pp = partial + (size_t)blockIdx.x * 3 * E;
+            pp[e] = g_;
+            pp[E + e] = b_;
+            pp[2 * E + e] = c_;
         }
+    }
+}
+
+// sum the per-block partials over blocks and accumulate into dgamma / dbeta / dcolsum
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int E,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dcolsum) {
+    __shared__ float red[8][32];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;  // 32 columns x 8 block lanes
+    const int j = blockIdx.x * 32 + cx;                      // index into the 3E partial columns
+    float s = 0.f;
+    if (j < 3 * E)
+        for (int b = ry; b < nblocks; b += 8) s += partial[(size_t)b * 3 * E + j];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && j < 3 * E) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][cx];
+        float* dst = j < E ? dgamma : (j < 2 * E ? dbeta : dcolsum);
+        if (dst) dst[j % E] += t;
     }
 }
 
@@ -163,13 +186,18 @@ extern "C" int vp_layernorm_fwd(const float* x, const float* gamma, const float*
 extern "C" int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* dx, void* dxb_bf16,
                                 const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
-                                float* dcolsum, int M, int E, hipStream_t stream) {
-    VP_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && (dx || dxb_bf16));
+                                float* dcolsum, int M, int E, float* workspace, size_t workspace_floats,
+                                hipStream_t stream) {
+    VP_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && (dx || dxb_bf16) && workspace);
     VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * MAXC);
     if (rowscale) VP_CHECK_ARG(rows_per_scale > 0);
     int blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;
+    if ((size_t)blocks * 3 * E > workspace_floats) blocks = (int)(workspace_floats / (3 * (size_t)E));
+    VP_CHECK_ARG(blocks >= 1);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)dy_bf16, x, mean, rstd, gamma,
-                       dres, dx, (bf16*)dxb_bf16, rowscale, rows_per_scale, dgamma, dbeta, dcolsum, M, E);
+                       dres, dx, (bf16*)dxb_bf16, rowscale, rows_per_scale, workspace, M, E);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * E + 31) / 32), dim3(256), 0, stream, workspace, blocks, E,
+                       dgamma, dbeta, dcolsum);
     VP_LAUNCH_RET();
 }

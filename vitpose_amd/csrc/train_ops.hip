@@ -82,12 +82,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int M, int C,
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const bf16* __restrict__ z, bf16* __restrict__ a,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, size_t n8, int C) {
+    // a thread's 8 channels only change when the grid stride is not a multiple of C (never for
+    // C | 2048): the per-channel coefficients stay in registers across iterations
+    int cc = -1;
+    float sc[8], sh[8];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 8) % C);
+        if (c != cc) {
+            cc = c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = scale[c + j]; sh[j] = shift[c + j]; }
+        }
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(z + i * 8);
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf((float)v[j] * scale[c + j] + shift[c + j], 0.f);
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(fmaf((float)v[j], sc[j], sh[j]), 0.f);
         *reinterpret_cast<bf16x8*>(a + i * 8) = o;
     }
 }
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
     }
 }
 
-// dz = gamma * invstd * (g - dbeta/M - xhat * dgamma/M)
+// dz = gamma * invstd * (g - dbeta/M - xhat * dgamma/M) = k1 * g - k2 - k3 * z  per channel
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ g, const bf16* __restrict__ z,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -149,17 +158,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, bf16* __restrict__ dz,
                                                            size_t n8, int C, float invM) {
+    int cc = -1;
+    float k1[8], k2[8], k3[8];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)((i * 8) % C);
+        if (c != cc) {
+            cc = c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float is = invstd[c + j], gi = gamma[c + j] * is;
+                const float dgm = dgamma[c + j] * invM * is;     // coefficient of (z - mean)
+                k1[j] = gi;
+                k3[j] = gi * dgm;
+                k2[j] = gi * (dbeta[c + j] * invM - dgm * mean[c + j]);
+            }
+        }
         const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + i * 8);
         const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + i * 8);
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float is = invstd[c + j];
-            const float xh = ((float)zv[j] - mean[c + j]) * is;
-            o[j] = (bf16)(gamma[c + j] * is * ((float)gv[j] - dbeta[c + j] * invM - xh * dgamma[c + j] * invM));
-        }
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(k1[j] * (float)gv[j] - k2[j] - k3[j] * (float)zv[j]);
         *reinterpret_cast<bf16x8*>(dz + i * 8) = o;
     }
 }

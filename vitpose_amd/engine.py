@@ -276,12 +276,13 @@ class VitRunner:
         dxn = ws.bf16('dxn', M, E)
         dao = ws.bf16('dao', M, E)
         dqkv = ws.bf16('dqkv', M, 3 * E)
+        lnws = ws.f32('ln_bwd_partials', 3 * E * 512)
         last = self.depth - 1
         x_last = ws.bufs[f'x_in.{self.depth}']
         if self.cfg.get('last_norm', True):
             plan.layernorm_bwd(dfeat, x_last, ws.bufs['mean_l'], ws.bufs['rstd_l'], self.w('last_norm.weight'),
                                None, dx_a, dxb, dp_scale(last, 1), T, self.g('last_norm.weight'),
-                               self.g('last_norm.bias'), self.g(f'blocks.{last}.mlp.fc2.bias'), M, E)
+                               self.g('last_norm.bias'), self.g(f'blocks.{last}.mlp.fc2.bias'), M, E, workspace=lnws)
         else:
             raise NotImplementedError('last_norm=False backward')
         dx = dx_a
@@ -305,7 +306,7 @@ class VitRunner:
             # LN2 backward, residual add, scaled bf16 copy for the attention branch, proj bias grad
             plan.layernorm_bwd(dxn, g['x_mid' + s], g['mean2' + s], g['rstd2' + s], self.w(b + 'norm2.weight'),
                                dx, other, dxb, dp_scale(i, 0), T, self.g(b + 'norm2.weight'),
-                               self.g(b + 'norm2.bias'), self.g(b + 'attn.proj.bias'), M, E)
+                               self.g(b + 'norm2.bias'), self.g(b + 'attn.proj.bias'), M, E, workspace=lnws)
             dx, other = other, dx
             # ---- attention branch
             plan.gemm(dxb, self.h(b + 'attn.proj.weight'), dao, M, E, E, ldx=E, ldy=E, ldo=E, y_kmajor=True)
@@ -323,7 +324,7 @@ class VitRunner:
             nxt_bias = self.g(f'blocks.{i - 1}.mlp.fc2.bias') if i > 0 else self.g('patch_embed.proj.bias')
             plan.layernorm_bwd(dxn, g['x_in' + s], g['mean1' + s], g['rstd1' + s], self.w(b + 'norm1.weight'),
                                dx, other, dxb, dp_scale(i - 1, 1), T, self.g(b + 'norm1.weight'),
-                               self.g(b + 'norm1.bias'), nxt_bias, M, E)
+                               self.g(b + 'norm1.bias'), nxt_bias, M, E, workspace=lnws)
             dx, other = other, dx
             if after_block is not None and i > 0:
                 # every gradient of blocks >= i is final here except fc2.bias of block i-1

@@ -114,10 +114,13 @@ class Plan:
                   M, E, eps, keep=(x, gamma, beta, y_bf16, y_f32, mean, rstd))
 
     def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, rows_per_scale,
-                      dgamma, dbeta, dcolsum, M, E):
+                      dgamma, dbeta, dcolsum, M, E, workspace=None):
+        if workspace is None:  # per-workgroup partial column sums
+            workspace = torch.empty(3 * E * 512, dtype=torch.float32, device=x.device)
         self._add('vp_layernorm_bwd', _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb),
-                  _p(rowscale), rows_per_scale, _p(dgamma), _p(dbeta), _p(dcolsum), M, E,
-                  keep=(dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, dgamma, dbeta, dcolsum))
+                  _p(rowscale), rows_per_scale, _p(dgamma), _p(dbeta), _p(dcolsum), M, E, _p(workspace),
+                  workspace.numel(),
+                  keep=(dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, dgamma, dbeta, dcolsum, workspace))
 
     def attention_fwd(self, qkv, out, lse, B, H, d, tokens, scale):
         self._add('vp_attention_fwd', _p(qkv), _p(out), _p(lse), B, H, d, tokens, scale, keep=(qkv, out, lse))
