@@ -75,6 +75,11 @@ typedef struct vp_gemm_args {
     /* optional output row remap (sub-pixel phases of a transposed conv): when out_row_div > 0,
      * row i of C is stored at row (i / div) * hi + (i % div) * lo + off of out / out2. */
     int out_row_div, out_row_hi, out_row_lo, out_row_off;
+    /* optional scratch (caller-owned, >= 32 MiB covers every shape): when given, the last partial
+     * round of tiles is cut along K so that it fills the chip, and a fix-up kernel applies the
+     * epilogue.  NULL = plain launch.  Launches sharing one scratch must be stream-ordered. */
+    float* tail_ws; size_t tail_ws_bytes;
+    int tail_force;              /* 1: always split the tail round when tail_ws is given (default: heuristic) */
 } vp_gemm_args;
 
 int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);

@@ -351,3 +351,18 @@ def test_adamw_matches_torch(dev):
     for i, (n, s) in enumerate(shapes):
         torch.testing.assert_close(st.view(n), ref[i].detach(), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(st.hview(n).float(), ref[i].detach().bfloat16().float(), rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize('xk,yk', [(False, False), (False, True)])
+def test_gemm_tail_tiles_split_along_k(dev, xk, yk):
+    """More tiles than the chip holds at once: the last partial round is cut along K and finished
+    by the fix-up kernel (integer data: bit-exact, with a fused epilogue on top)."""
+    from vitpose_amd import _lib
+    M, N, K = 66 * 128 + 40, 1024, 512          # 67 x 8 = 536 tiles > 512 resident workgroups
+    X, Y = ints((M, K), dev, seed=21), ints((N, K), dev, seed=22)
+    bias = ints((N,), dev, seed=23)
+    ys = (Y.t() if yk else Y).contiguous().bfloat16()
+    out = torch.full((M, N), float('nan'), device=dev)
+    run(lambda p: p.gemm(X.bfloat16(), ys, out, M, N, K, ldx=K, ldy=ys.shape[1], ldo=N, y_kmajor=yk,
+                         epilogue=_lib.VP_EPI_F32, bias=bias, tail_force=True))
+    assert torch.equal(out, X @ Y.t() + bias)

@@ -83,6 +83,12 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int s, i
     }
 }
 
+struct Tail {
+    int full;   // workgroups [0, full) compute whole tiles
+    int split;  // K slices per tail tile (<= 1: no tail handling)
+    float* ws;  // [tail tiles * split][16 fragments][256 threads] f32x4 partials
+};
+
 struct Epi {
     int kind;
     void* out; int ldo;
@@ -199,24 +205,37 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[4][4], i
 
 template <bool XKMAJ, bool YKMAJ, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y, int M, int N, int K,
-                                                           int tiles_n, int ntiles, int ksplit_tiles, Epi e) {
+                                                           int tiles_n, int ntiles, int ksplit_tiles, Epi e,
+                                                           Tail tl) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+
+    // Wave quantisation: the chip holds `slots` workgroups at once, so the last ntiles % slots tiles
+    // would run as a mostly empty round.  Those tail tiles are instead cut along K into tl.split
+    // slices (one workgroup each, all resident together); their f32 partials go to tl.ws and
+    // gemm_tail_fixup sums them and applies the epilogue.
+    int vb = blockIdx.x, tz = 0;
+    const bool tail = tl.split > 1 && (int)blockIdx.x >= tl.full;
+    if (tail) {
+        const int j = blockIdx.x - tl.full;
+        vb = tl.full + j / tl.split;
+        tz = j - (j / tl.split) * tl.split;
+    }
 
     // tile order: the N tiles of one 128-row panel are consecutive, and each XCD
     // (blocks congruent mod 8) gets a contiguous chunk of that order
     // ... and inside it tiles are walked in groups of 8 row panels, column by column, so the ~64
     // workgroups an XCD runs at once cover an 8x8 patch of tiles: 16 operand panels shared
     // through that XCD's 4 MiB L2 instead of a few row panels against the whole weight matrix
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int t = xcd_remap(vb, ntiles);
     const int tiles_m = ntiles / tiles_n;
     const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
     const int gm = min(tiles_m - gid * 8, 8);
     const int i0 = (gid * 8 + tin % gm) * BM, j0 = (tin / gm) * BN;
     const int nk_all = K / BK;
-    const int kt0 = blockIdx.y * ksplit_tiles;
-    const int kt1 = min(nk_all, kt0 + ksplit_tiles);
+    const int kt0 = tail ? (tz * nk_all) / tl.split : blockIdx.y * ksplit_tiles;
+    const int kt1 = tail ? ((tz + 1) * nk_all) / tl.split : min(nk_all, kt0 + ksplit_tiles);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -262,7 +281,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
             __syncthreads();
         }
     }
+    if (tail) {
+        f32x4* w = reinterpret_cast<f32x4*>(tl.ws) + (size_t)(blockIdx.x - tl.full) * 16 * NTHREADS + tid;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w[(a * 4 + b) * NTHREADS] = acc[a][b];
+        return;
+    }
     run_epilogue<EPI>(e, acc, i0, j0, wm, wn, lane, M, N);
+}
+
+// One workgroup per tail tile: sum the K-slice partials (same thread <-> fragment mapping as
+// the GEMM kernel) and run the fused epilogue.
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_tail_fixup(int M, int N, int tiles_n, int ntiles, Epi e, Tail tl) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int t = xcd_remap(tl.full + blockIdx.x, ntiles);
+    const int tiles_m = ntiles / tiles_n;
+    const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
+    const int gm = min(tiles_m - gid * 8, 8);
+    const int i0 = (gid * 8 + tin % gm) * BM, j0 = (tin / gm) * BN;
+    f32x4 acc[4][4];
+    const f32x4* w = reinterpret_cast<const f32x4*>(tl.ws) + (size_t)blockIdx.x * tl.split * 16 * NTHREADS + tid;
+    // few workgroups run here, so keep many loads in flight per thread: all (b, z) partials of
+    // one fragment row are fetched together (split <= 8; absent slices read slice 0 and are masked)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        f32x4 part[4][8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int z = 0; z < 8; ++z)
+                part[b][z] = w[((size_t)(z < tl.split ? z : 0) * 16 + a * 4 + b) * NTHREADS];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4 s = part[b][0];
+#pragma unroll
+            for (int z = 1; z < 8; ++z)
+                if (z < tl.split) s += part[b][z];
+            acc[a][b] = s;
+        }
+    }
+    run_epilogue<EPI>(e, acc, i0, j0, wm, wn, lane, M, N);
+}
+
+inline int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
 }
 
 template <bool XK, bool YK>
@@ -279,10 +354,31 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
     if (a->epilogue != VP_EPI_SPLITK_F32) split = 1;
     const int ksplit_tiles = (nk + split - 1) / split;
     dim3 grid(ntiles, split);
+    // tail handling (see gemm_kernel): only when a workspace is supplied and it pays
+    Tail tl{ntiles, 1, nullptr};
+    const int slots = 2 * num_cus();
+    const int ntail = ntiles % slots;
+    // measured on ViTPose-B shapes (12288 rows): the slab round trip + fix-up launch costs ~10-20 us,
+    // which only pays for long reductions with the (slower) transposed-read Y operand, or on request
+    const bool worth = a->tail_force || (YK && nk >= 32);
+    if (worth && a->epilogue != VP_EPI_SPLITK_F32 && a->tail_ws && ntiles > slots && ntail > 0 &&
+        ntail <= (slots * 3) / 4 && nk >= 4) {
+        int ts = slots / ntail;
+        if (ts > nk / 2) ts = nk / 2;  // at least two K steps per slice
+        if (ts > 8) ts = 8;
+        const size_t need = (size_t)ntail * ts * 16 * NTHREADS * sizeof(f32x4);
+        if (ts >= 2 && need <= a->tail_ws_bytes) {
+            tl = Tail{ntiles - ntail, ts, a->tail_ws};
+            grid = dim3(tl.full + ntail * ts, 1);
+        }
+    }
 #define VP_GEMM_CASE(EPI)                                                                         \
     case EPI:                                                                                     \
         hipLaunchKernelGGL((gemm_kernel<XK, YK, EPI>), grid, dim3(NTHREADS), 0, st, X, Y, a->M,   \
-                           a->N, a->K, tiles_n, ntiles, ksplit_tiles, e);                         \
+                           a->N, a->K, tiles_n, ntiles, ksplit_tiles, e, tl);                     \
+        if (tl.split > 1)                                                                         \
+            hipLaunchKernelGGL((gemm_tail_fixup<EPI>), dim3(ntiles - tl.full), dim3(NTHREADS), 0, \
+                               st, a->M, a->N, tiles_n, ntiles, e, tl);                           \
         break;
     switch (a->epilogue) {
         VP_GEMM_CASE(VP_EPI_BF16)

@@ -32,12 +32,24 @@ def _chk(t, dtype, name):
         raise ValueError(f'{name}: must be contiguous')
 
 
+_TAIL_WS = {}
+
+
+def _tail_workspace(device):
+    """One 32 MiB scratch per device for the GEMM tail-tile partial sums (launches are stream-ordered)."""
+    key = (device.type, device.index)
+    if key not in _TAIL_WS:
+        _TAIL_WS[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+    return _TAIL_WS[key]
+
+
 class Plan:
     def __init__(self):
         self.L = _lib.lib()
         self.calls = []     # (name, cfunc, args)
         self.keep = []      # tensors / ctypes objects that must outlive the plan
         self.tags = {}      # call index -> (x_kmajor, y_kmajor, epilogue, M, N, K) of GEMM launches
+        self.use_tail_split = True
 
     # -- replay --
     def run(self, stream=None):
@@ -77,8 +89,9 @@ class Plan:
     def gemm(self, x, y, out, M, N, K, *, ldx, ldy, ldo, x_kmajor=False, y_kmajor=False,
              epilogue=_lib.VP_EPI_BF16, out2=None, bias=None, colscale=None, resid=None,
              rowscale=None, rows_per_scale=0, aux=None, ldaux=0, pos=None, pos_rows=0, split_k=1,
-             row_map=None, split_stride=0):
+             row_map=None, split_stride=0, tail_force=False):
         a = GemmArgs()
+        a.tail_force = int(tail_force)
         a.split_stride = split_stride
         a.M, a.N, a.K = M, N, K
         a.x, a.ldx, a.x_kmajor = x.data_ptr(), ldx, int(x_kmajor)
@@ -91,6 +104,10 @@ class Plan:
         a.rows_per_scale, a.ldaux, a.pos_rows, a.split_k = rows_per_scale, ldaux, pos_rows, split_k
         if row_map is not None:
             a.out_row_div, a.out_row_hi, a.out_row_lo, a.out_row_off = row_map
+        if self.use_tail_split and epilogue != _lib.VP_EPI_SPLITK_F32:
+            tw = _tail_workspace(out.device)
+            a.tail_ws, a.tail_ws_bytes = tw.data_ptr(), tw.numel() * 4
+            self.keep.append(tw)
         self.tags[len(self.calls)] = (int(x_kmajor), int(y_kmajor), epilogue, M, N, K)
         self._add('vp_gemm_bf16', ctypes.byref(a),
                   keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
