@@ -163,6 +163,10 @@ int vp_bn_bwd(const void* g, const void* z, const float* mean, const float* invs
  * *loss += loss value; dheat [B*HW][ldh] bf16 = dL/dheat (optional). */
 int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, const float* target, const float* tw,
                     float* loss, void* dheat, int B, int K, int HW, float loss_weight, vp_stream_t stream);
+/* The same loss on NCHW f32 heatmaps (the layout TopdownHeatmapSimpleHead.forward returns):
+ * *loss += value; dpred (optional, NCHW f32) = dL/dpred.  tw [B][K] or NULL (use_target_weight=False). */
+int vp_mse_loss_nchw(const float* pred, const float* target, const float* tw, float* loss, float* dpred,
+                     int B, int K, int HW, float loss_weight, vp_stream_t stream);
 /* _get_max_preds (mmpose/core/evaluation/top_down_eval.py:63-95): first arg-max of each row. */
 int vp_argmax_rows(const float* x, int rows, int L, int* idx, float* val, vp_stream_t stream);
 
