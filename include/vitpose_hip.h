@@ -156,6 +156,32 @@ int vp_bn_apply_relu(const void* z, void* a, const float* scale, const float* sh
 int vp_bn_bwd(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
               float* dgamma, float* dbeta, void* dz, int M, int C, vp_stream_t stream);
 
+/* ------------------------------------------------------- simple decoder --------
+ * TopdownHeatmapSimpleHead with upsample > 0 and/or final_conv_kernel = 3
+ * (topdown_heatmap_simple_head.py:278-287 `_transform_inputs`: ReLU + bilinear resize; :132-139 final
+ * Conv2d).  The channel contraction runs first on the low-resolution grid as a GEMM,
+ * G[(b,j)][t*kpad + k] = sum_c W[k][c][tap t] * relu(feat)[b][j][c]; these kernels do the rest:
+ *   fwd: out[b][k][y][x] (NCHW f32) = bias[k] + sum_t Up(G_t)[y + ty - p][x + tx - p][k], p = (ksize-1)/2,
+ *        zero outside the up-sampled grid; yi/yw [Ho][2], xi/xw [Wo][2] = the two source rows / columns
+ *        and weights of every output coordinate (F.interpolate bilinear; built by the host).
+ *   bwd: dG (bf16 [B*Hg*Wg][ldg], columns >= ksize^2*kpad zeroed) = the transpose of fwd applied to dout;
+ *        tyi/tyw [Hg][Ly], txi/txw [Wg][Lx] list, per source row / column, the output coordinates that
+ *        interpolate from it and their weights (index -1 = empty slot).
+ * kpad (the per-tap column count of G, >= K) must be 20, 32 or 64. */
+int vp_upconv_fwd(const float* G, int ldg, const float* bias, float* out, const int* yi, const float* yw,
+                  const int* xi, const float* xw, int B, int K, int kpad, int Hg, int Wg, int Ho, int Wo,
+                  int ksize, vp_stream_t stream);
+int vp_upconv_bwd(const float* dout, void* dG_bf16, int ldg, const int* tyi, const float* tyw, const int* txi,
+                  const float* txw, int Ly, int Lx, int B, int K, int kpad, int Hg, int Wg, int Ho, int Wo,
+                  int ksize, vp_stream_t stream);
+/* out[k] += sum_b sum_p x[b][k][p] (bias gradient of a conv on NCHW f32 maps). */
+int vp_plane_sum_f32(const float* x, float* out, int B, int K, int HW, vp_stream_t stream);
+/* y = max(x, 0) on n bf16 elements (F.relu of `_transform_inputs`, topdown_heatmap_simple_head.py:282). */
+int vp_relu_bf16(const void* x, void* y, size_t n, vp_stream_t stream);
+/* NCHW f32 [B][C][HW] -> channels-last bf16 [B*HW][ld] (columns >= C zeroed): the entry bridge of a
+ * head fed by a foreign NCHW backbone, and of NCHW heat-map gradients (vit.py:330 is the inverse). */
+int vp_nchw_to_cl_bf16(const float* src, void* dst_bf16, int B, int C, int HW, int ld, vp_stream_t stream);
+
 /* ------------------------------------------------------------------ Loss --------
  * JointsMSELoss.forward (mmpose/models/losses/mse_loss.py:24-44) fused with its gradient and the
  * channels-last -> NCHW copy of the heatmaps.  heat [B*HW][ldh] f32 (first K columns valid);

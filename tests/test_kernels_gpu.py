@@ -366,3 +366,77 @@ def test_gemm_tail_tiles_split_along_k(dev, xk, yk):
     run(lambda p: p.gemm(X.bfloat16(), ys, out, M, N, K, ldx=K, ldy=ys.shape[1], ldo=N, y_kmajor=yk,
                          epilogue=_lib.VP_EPI_F32, bias=bias, tail_force=True))
     assert torch.equal(out, X @ Y.t() + bias)
+
+
+@pytest.mark.parametrize('upsample,fk,align', [(4, 3, False), (4, 1, False), (0, 3, False), (2, 3, True)])
+def test_simple_decoder_fwd_bwd(dev, upsample, fk, align):
+    """ReLU -> bilinear resize -> Conv2d (topdown_heatmap_simple_head.py:278-287,132-139) as
+    GEMM-on-the-low-res-grid + interpolate-shift-sum, against torch fp32 autograd on the same
+    bf16-rounded feature / weights.  Tolerance: bf16 rounding of G's operands only (f32 accumulation):
+    2e-2 relative to the tensor's largest magnitude."""
+    import torch.nn.functional as F
+    from vitpose_amd.engine import ParamStore, Workspace
+    from vitpose_amd.head_engine import HeadRunner, head_param_shapes
+    from vitpose_amd.plan import Plan
+    B, C, K, Hg, Wg = 2, 64, 17, 16, 12
+    cfg = dict(in_channels=C, out_channels=K, num_deconv_layers=0, num_deconv_filters=[], num_deconv_kernels=[],
+               upsample=upsample, align_corners=align, extra=dict(final_conv_kernel=fk))
+    params, _ = head_param_shapes(cfg)
+    st = ParamStore(params, dev)
+    Wt = (rnd((K, C, fk, fk), dev, 1, 0.2)).bfloat16().float()
+    bias = rnd((K,), dev, 2)
+    st.load({'final_layer.weight': Wt, 'final_layer.bias': bias})
+    hr = HeadRunner(cfg, st, {}, (Hg, Wg))
+    prep = Plan()
+    hr.record_weight_prep(prep)
+    prep.run()
+    feat = rnd((B, C, Hg, Wg), dev, 3).bfloat16().float()
+    feat_cl = feat.permute(0, 2, 3, 1).reshape(B * Hg * Wg, C).contiguous().bfloat16()
+    Ho, Wo = hr.out_grid
+    heat = torch.empty(B, K, Ho, Wo, device=dev)
+    target = rnd((B, K, Ho, Wo), dev, 4)
+    tw = (rnd((B, K), dev, 5) > -0.5).float()
+    loss = torch.zeros(1, device=dev)
+    ws = Workspace(dev)
+    plan = Plan()
+    plan.memset0(st.grad)
+    dpred = hr.record_forward(plan, ws, feat_cl, B, True, heat, target, tw, loss, want_grad=True)
+    dfeat = hr.record_backward(plan, ws, feat_cl, dpred, B)
+    plan.run()
+    torch.cuda.synchronize()
+    # torch reference
+    f = feat.clone().requires_grad_()
+    Wr, br = Wt.clone().requires_grad_(), bias.clone().requires_grad_()
+    x = f
+    if upsample > 0:
+        x = F.interpolate(F.relu(x), scale_factor=upsample, mode='bilinear', align_corners=align)
+    ref = F.conv2d(x, Wr, br, padding=1 if fk == 3 else 0)
+    w = tw.view(B, K, 1, 1)
+    rl = ((w * (ref - target)) ** 2).mean()
+    rl.backward()
+
+    def chk(got, want, tol=2e-2):
+        err = (got.float() - want).abs().max().item()
+        assert err <= tol * want.abs().max().item() + 1e-6, (err, want.abs().max().item())
+    chk(heat, ref.detach())
+    assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
+    chk(dfeat.view(B, Hg, Wg, C).permute(0, 3, 1, 2), f.grad, 3e-2)
+    chk(st.gview('final_layer.weight'), Wr.grad, 3e-2)
+    chk(st.gview('final_layer.bias'), br.grad, 3e-2)
+
+
+def test_nchw_bridges_and_relu(dev):
+    from vitpose_amd import _lib
+    B, C, HW, ld = 3, 17, 48, 64
+    src = rnd((B, C, HW), dev, 1)
+    dst = torch.full((B * HW, ld), float('nan'), device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.nchw_to_cl(src, dst, B, C, HW, ld))
+    assert torch.equal(dst.view(B, HW, ld)[:, :, :C].float(), src.bfloat16().float().transpose(1, 2))
+    assert torch.equal(dst.view(B, HW, ld)[:, :, C:].float(), torch.zeros(B, HW, ld - C, device=dev))
+    x = rnd((4096,), dev, 2).bfloat16()
+    y = torch.empty_like(x)
+    run(lambda p: p.relu_bf16(x, y, x.numel()))
+    assert torch.equal(y, torch.relu(x))
+    s = torch.zeros(C, device=dev)
+    run(lambda p: p.plane_sum(src, s, B, C, HW))
+    torch.testing.assert_close(s, src.sum((0, 2)), rtol=1e-5, atol=1e-5)

@@ -199,3 +199,38 @@ def test_train_step_updates_weights_like_torch_adamw(dev):
     # Adam's first update is lr * g / (|g| + eps): sign-like, so the 1-2 % bf16 gradient noise
     # flips near-zero entries; 0.17 measured, a wrong gradient anywhere gives ~1.4
     assert rel < 0.3
+
+
+def test_vitpose_s_simple_decoder_vs_reference_golden(dev, golden_dir):
+    """BASELINE config 1 (ViTPose-S + simple decoder, batch 1): the reference source ran it on the
+    CPU (golden), the HIP path runs it on the GPU.  O(1) heat maps, bf16 operands: relative bound."""
+    g = np.load(os.path.join(golden_dir, 'vitpose_s_simple_eval.npz'))
+    vcfg, hs = O.vit_cfg('S'), O.simple_head_cfg(384)
+    eng = make_engine(vcfg, hs, O.synth_vit_weights(vcfg, seed=20), O.synth_head_weights(hs, seed=23), dev)
+    img, _, _ = O.synth_batch(2, seed=22)
+    heat = eng.infer(img[:1].to(dev)).cpu()
+    assert heat.shape == (1, 17, 64, 48)
+    rel, mx = relerr(heat, g['heat'])
+    print(f'ViTPose-S simple decoder, |ref|max {np.abs(g["heat"]).max():.2f}: rel {rel:.2e} maxabs {mx:.2e}')
+    assert rel < 3e-2, (rel, mx)
+
+
+def test_simple_decoder_train_step_vs_oracle(dev):
+    """Forward + backward of backbone + simple decoder against the oracle under torch autograd."""
+    hc = O.simple_head_cfg(64)
+    bb, hd = O.synth_vit_weights(TOY, seed=5), O.synth_head_weights(hc, seed=6)
+    eng = make_engine(TOY, hc, bb, hd, dev)
+    img, target, tw = O.synth_batch(2, seed=7)
+    loss, heat = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+    torch.cuda.synchronize()
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    hdr = {k: v.clone().requires_grad_() for k, v in hd.items()}
+    ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), hc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
+    for n in ('final_layer.weight', 'final_layer.bias'):
+        assert relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0] < 5e-2, n
+    for n in ('blocks.1.mlp.fc2.weight', 'blocks.0.attn.qkv.weight', 'patch_embed.proj.weight', 'pos_embed'):
+        assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 8e-2, n

@@ -55,6 +55,11 @@ SIGNATURES = {
     'vp_bn_finalize': [P, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P],
     'vp_bn_apply_relu': [P, P, P, P, c_int, c_int, P],
     'vp_bn_bwd': [P, P, P, P, P, P, P, P, c_int, c_int, P],
+    'vp_upconv_fwd': [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    'vp_upconv_bwd': [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    'vp_plane_sum_f32': [P, P, c_int, c_int, c_int, P],
+    'vp_relu_bf16': [P, P, c_size_t, P],
+    'vp_nchw_to_cl_bf16': [P, P, c_int, c_int, c_int, c_int, P],
     'vp_heatmap_loss': [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'vp_mse_loss_nchw': [P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'vp_argmax_rows': [P, c_int, c_int, P, P, P],

@@ -3,6 +3,10 @@
 Classic decoder: each ConvTranspose2d(k=4, s=2, p=1, bias=False) is four sub-pixel
 GEMMs (one per output parity), BatchNorm is a column reduction + folded scale/shift,
 the final 1x1 conv a skinny GEMM (17 output channels padded to 64 columns).
+
+Simple decoder (`upsample` > 0 and / or a 3x3 final conv): ReLU -> bilinear resize -> conv is
+evaluated as a GEMM on the low-resolution grid (one column block per conv tap) followed by an
+interpolate-shift-sum kernel; the up-sampled feature map is never materialised.
 """
 import math
 from typing import List, Optional, Sequence, Tuple
@@ -35,6 +39,39 @@ def head_param_shapes(cfg) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[Tupl
     return params, bufs
 
 
+def bilinear_tables(n_in: int, n_out: int, scale_factor, align_corners: bool):
+    """Source index pairs / weights of torch's bilinear F.interpolate along one axis
+    (the reference's `resize`, mmpose/models/utils/ops.py:7-29), and the transposed lists.
+    Returns (idx [n_out][2] int32, w [n_out][2] f32, tidx [n_in][L] int32, tw [n_in][L] f32)."""
+    idx = torch.zeros(n_out, 2, dtype=torch.int32)
+    w = torch.zeros(n_out, 2, dtype=torch.float32)
+    for u in range(n_out):
+        if n_out == n_in:
+            src = float(u)
+        elif align_corners:
+            src = u * (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
+        else:
+            sc = (1.0 / scale_factor) if scale_factor else n_in / n_out
+            src = max((u + 0.5) * sc - 0.5, 0.0)
+        i0 = min(int(math.floor(src)), n_in - 1)
+        i1 = min(i0 + 1, n_in - 1)
+        l1 = src - i0
+        idx[u, 0], idx[u, 1] = i0, i1
+        w[u, 0], w[u, 1] = 1.0 - l1, l1
+    lists = [[] for _ in range(n_in)]
+    for u in range(n_out):
+        for a in range(2):
+            if w[u, a] != 0:
+                lists[int(idx[u, a])].append((u, float(w[u, a])))
+    L = max(1, max(len(l) for l in lists))
+    tidx = torch.full((n_in, L), -1, dtype=torch.int32)
+    tw = torch.zeros(n_in, L, dtype=torch.float32)
+    for j, l in enumerate(lists):
+        for a, (u, c) in enumerate(l):
+            tidx[j, a], tw[j, a] = u, c
+    return idx, w, tidx, tw
+
+
 class HeadRunner:
     def __init__(self, cfg: dict, store: ParamStore, buffers: dict, grid_hw: Tuple[int, int], prefix: str = ''):
         """`buffers`: name -> f32 device tensor for the BN running statistics."""
@@ -53,9 +90,15 @@ class HeadRunner:
                 raise NotImplementedError('HIP head covers deconv kernel size 4 (the ViTPose configs)')
             if self.fk != 1 or self.upsample:
                 raise NotImplementedError('deconv head with final_conv_kernel != 1 or upsample')
+        if self.fk not in (1, 3):
+            raise NotImplementedError('HIP head needs a final conv (final_conv_kernel 1 or 3)')
         if self.K > KPAD:
             raise NotImplementedError('more than 64 keypoints')
         dev = store.device
+        self.simple = self.nl == 0 and (self.fk == 3 or self.upsample > 0)
+        if self.simple:
+            self._init_simple(dev)
+            return
         self.chans = [self.cin] + [cfg['num_deconv_filters'][i] for i in range(self.nl)]
         # compute-layout weight copies (bf16): sub-pixel phase matrices and the 16-tap matrix
         self.wph = [torch.empty(4, self.chans[l + 1], 4 * self.chans[l], dtype=torch.bfloat16, device=dev)
@@ -75,6 +118,24 @@ class HeadRunner:
         self.bn_invstd = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
         self.bn_sums = [torch.zeros(2 * c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
 
+    def _init_simple(self, dev):
+        cfg = self.cfg
+        self.chans = [self.cin]
+        s = self.upsample if self.upsample > 0 else 1
+        self.Ho, self.Wo = int(self.Hg * s), int(self.Wg * s)
+        self.taps = self.fk * self.fk
+        self.kp = 20 if self.K <= 20 else (32 if self.K <= 32 else 64)   # per-tap columns of G
+        self.ng = self.taps * self.kp                                  # valid columns of G
+        self.ngp = (self.ng + 63) // 64 * 64                           # as a reduction extent
+        ac = bool(cfg.get('align_corners', False))
+        ty = bilinear_tables(self.Hg, self.Ho, self.upsample or None, ac)
+        tx = bilinear_tables(self.Wg, self.Wo, self.upsample or None, ac)
+        self.tabs = tuple(t.reshape(-1).contiguous().to(dev) for t in (ty[0], ty[1], tx[0], tx[1]))
+        self.ttabs = tuple(t.contiguous().to(dev) for t in (ty[2], ty[3], tx[2], tx[3]))
+        # wcat[t*kp + k][c] = W[k][c][tap t] (zero rows elsewhere); dwcat its f32 gradient
+        self.wcat = torch.zeros(self.ngp, self.cin, dtype=torch.bfloat16, device=dev)
+        self.dwcat = torch.zeros(self.ngp, self.cin, dtype=torch.float32, device=dev)
+
     def w(self, n):
         return self.store.view(self.pre + n)
 
@@ -84,8 +145,21 @@ class HeadRunner:
     def buf(self, n):
         return self.buffers[self.pre + n]
 
+    @property
+    def out_grid(self):
+        """(H, W) of the heat maps."""
+        if self.simple:
+            return self.Ho, self.Wo
+        return self.Hg * 2 ** self.nl, self.Wg * 2 ** self.nl
+
     # -- weight re-layout (recorded once, replayed after every weight update) --
     def record_weight_prep(self, plan: Plan):
+        if self.simple:
+            W = self.w('final_layer.weight')  # [K][C][fk][fk] f32
+            for t in range(self.taps):
+                plan.strided_cast(W.view(-1)[t:], self.wcat[t * self.kp:], (1, 1, self.K, self.cin),
+                                  (0, 0, self.cin * self.taps, self.taps))
+            return
         for l in range(self.nl):
             W = self.w(f'deconv_layers.{3 * l}.weight')  # [Cin][Cout][4][4] f32
             ci, co = self.chans[l], self.chans[l + 1]
@@ -106,6 +180,8 @@ class HeadRunner:
                        heat_nchw: torch.Tensor, target=None, tw=None, loss=None, want_grad=False,
                        loss_weight: float = 1.0):
         """feat: bf16 channels-last [B*Hg*Wg][Cin].  Writes heat_nchw [B][K][4Hg*4Wg...] f32."""
+        if self.simple:
+            return self._record_forward_simple(plan, ws, feat, B, heat_nchw, target, tw, loss, want_grad, loss_weight)
         H, W = self.Hg, self.Wg
         a = feat
         sfx = (lambda l: f'.{l}') if training else (lambda l: '')
@@ -151,8 +227,62 @@ class HeadRunner:
         self.out_hw = (H, W)
         return dheat
 
+    def _record_forward_simple(self, plan, ws, feat, B, heat_nchw, target, tw, loss, want_grad, loss_weight):
+        M, C = B * self.Hg * self.Wg, self.cin
+        if self.upsample > 0:
+            r = ws.bf16('relu_feat', M, C)
+            plan.relu_bf16(feat, r, M * C)
+        else:
+            r = feat
+        G = ws.f32('upconv_G', M, self.ng)
+        plan.gemm(r, self.wcat, G, M, self.ng, C, ldx=C, ldy=C, ldo=self.ng, epilogue=_lib.VP_EPI_F32)
+        plan.upconv_fwd(G, self.ng, self.w('final_layer.bias'), heat_nchw, self.tabs, B, self.K, self.kp,
+                        self.Hg, self.Wg, self.Ho, self.Wo, self.fk)
+        self._relu_feat = r
+        self.out_hw = (self.Ho, self.Wo)
+        dpred = None
+        if target is not None:
+            dpred = ws.f32('dheat_nchw', B, self.K, self.Ho, self.Wo) if want_grad else None
+            plan.memset0(loss)
+            plan.mse_loss_nchw(heat_nchw, target, tw, loss, dpred, B, self.K, self.Ho * self.Wo, loss_weight)
+        return dpred
+
+    def _record_backward_simple(self, plan, ws, feat, dpred, B):
+        """dpred: NCHW f32 gradient wrt the heat maps."""
+        M, C = B * self.Hg * self.Wg, self.cin
+        plan.plane_sum(dpred, self.g('final_layer.bias'), B, self.K, self.Ho * self.Wo)
+        dG = ws.bf16('upconv_dG', M, self.ngp)
+        plan.upconv_bwd(dpred, dG, self.ngp, self.ttabs, B, self.K, self.kp, self.Hg, self.Wg, self.Ho, self.Wo,
+                        self.fk)
+        slab = ws.f32('splitk_slab_head', _slab_elems(self.ngp * C, M))
+        plan.wgrad(dG, self._relu_feat, self.dwcat, self.ngp, C, M, ldx=self.ngp, ldy=C,
+                   split_k=_split_k(self.ngp, C, M), slab=slab)
+        gW, dwcat, K, kp, taps, fk = self.g('final_layer.weight'), self.dwcat, self.K, self.kp, self.taps, self.fk
+
+        def final_grads():
+            gW.add_(dwcat[:taps * kp].view(taps, kp, C)[:, :K].permute(1, 2, 0).reshape(K, C, fk, fk))
+        plan.host(final_grads)
+        g = ws.bf16('hg', M, C)
+        if self.upsample > 0:
+            plan.gemm(dG, self.wcat, g, M, C, self.ngp, ldx=self.ngp, ldy=C, ldo=C, y_kmajor=True,
+                      epilogue=_lib.VP_EPI_DRELU, aux=feat, ldaux=C)
+        else:
+            plan.gemm(dG, self.wcat, g, M, C, self.ngp, ldx=self.ngp, ldy=C, ldo=C, y_kmajor=True)
+        return g
+
+    def record_backward_nchw(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat_nchw: torch.Tensor, B: int):
+        """Backward from an NCHW f32 heat-map gradient (stand-alone head module)."""
+        if self.simple:
+            return self._record_backward_simple(plan, ws, feat, dheat_nchw, B)
+        H, W = self.out_hw
+        dheat = ws.bf16('dheat', B * H * W, KPAD)
+        plan.nchw_to_cl(dheat_nchw, dheat, B, self.K, H * W, KPAD)
+        return self.record_backward(plan, ws, feat, dheat, B)
+
     # -- backward: returns the bf16 gradient wrt `feat` --
     def record_backward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat: torch.Tensor, B: int):
+        if self.simple:
+            return self._record_backward_simple(plan, ws, feat, dheat, B)
         H, W = self.out_hw
         Mh = B * H * W
         cl = self.chans[-1]

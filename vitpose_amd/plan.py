@@ -191,6 +191,30 @@ class Plan:
         self._add('vp_heatmap_loss', _p(heat), ldh, _p(heat_nchw), _p(target), _p(tw), _p(loss), _p(dheat),
                   B, K, HW, loss_weight, keep=(heat, heat_nchw, target, tw, loss, dheat))
 
+    def mse_loss_nchw(self, pred, target, tw, loss, dpred, B, K, HW, loss_weight):
+        self._add('vp_mse_loss_nchw', _p(pred), _p(target), _p(tw), _p(loss), _p(dpred), B, K, HW, loss_weight,
+                  keep=(pred, target, tw, loss, dpred))
+
+    def upconv_fwd(self, G, ldg, bias, out, tabs, B, K, kpad, Hg, Wg, Ho, Wo, ksize):
+        yi, yw, xi, xw = tabs
+        self._add('vp_upconv_fwd', _p(G), ldg, _p(bias), _p(out), _p(yi), _p(yw), _p(xi), _p(xw), B, K, kpad,
+                  Hg, Wg, Ho, Wo, ksize, keep=(G, bias, out, yi, yw, xi, xw))
+
+    def upconv_bwd(self, dout, dG, ldg, ttabs, B, K, kpad, Hg, Wg, Ho, Wo, ksize):
+        tyi, tyw, txi, txw = ttabs
+        self._add('vp_upconv_bwd', _p(dout), _p(dG), ldg, _p(tyi), _p(tyw), _p(txi), _p(txw), tyi.shape[1],
+                  txi.shape[1], B, K, kpad, Hg, Wg, Ho, Wo, ksize, keep=(dout, dG, tyi, tyw, txi, txw))
+
+    def plane_sum(self, x, out, B, K, HW):
+        self._add('vp_plane_sum_f32', _p(x), _p(out), B, K, HW, keep=(x, out))
+
+    def relu_bf16(self, x, y, n):
+        self._add('vp_relu_bf16', _p(x), _p(y), n, keep=(x, y))
+
+    def nchw_to_cl(self, src, dst, B, C, HW, ld):
+        _chk(src, torch.float32, 'src')
+        self._add('vp_nchw_to_cl_bf16', _p(src), _p(dst), B, C, HW, ld, keep=(src, dst))
+
     def argmax_rows(self, x, rows, L, idx, val):
         self._add('vp_argmax_rows', _p(x), rows, L, _p(idx), _p(val), keep=(x, idx, val))
 

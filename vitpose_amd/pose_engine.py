@@ -81,7 +81,7 @@ class PoseEngine:
             img = ws.f32('img', B, self.vit.C, H, W)
             plan = Plan()
             feat = self.vit.record_forward(plan, ws, img, B, training=False)
-            oh, ow = self.vit.Hp * 2 ** self.head.nl, self.vit.Wp * 2 ** self.head.nl
+            oh, ow = self.head.out_grid
             heat = ws.f32('heat', B, self.K, oh, ow)
             self.head.record_forward(plan, ws, feat, B, False, heat)
             self.plans[key] = (plan, img, heat)
@@ -103,7 +103,7 @@ class PoseEngine:
         if key not in self.plans:
             ws = self.ws_train
             H, W = self.vit.img_hw
-            oh, ow = self.vit.Hp * 2 ** self.head.nl, self.vit.Wp * 2 ** self.head.nl
+            oh, ow = self.head.out_grid
             io = dict(img=ws.f32('img', B, self.vit.C, H, W), target=ws.f32('target', B, self.K, oh, ow),
                       tw=ws.f32('tw', B, self.K), heat=ws.f32('heat', B, self.K, oh, ow),
                       loss=ws.f32('loss', 1), dp=ws.f32('dp', self.vit.depth, 2, B))
