@@ -1,0 +1,273 @@
+"""The drop-in model classes (vitpose_amd.models) on the GPU, against the oracle and the goldens:
+the reference's own shape tests (tests/test_models/test_top_down_head.py:235-262) and known-answer
+tests (tests/test_losses/test_top_down_losses.py:27-43, tests/test_evaluation/test_top_down_eval.py:11-26),
+module-by-module autograd parity, and the fused TopDown train / test call contract."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitpose_oracle as O
+
+pytestmark = pytest.mark.gpu
+LOSS = dict(type='JointsMSELoss', use_target_weight=True)
+TOY = dict(img_size=(256, 192), patch_size=16, in_chans=3, embed_dim=64, depth=2, num_heads=2,
+           mlp_ratio=4, qkv_bias=True, ratio=1, last_norm=True, drop_path_rate=0.0)
+PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def toy_model(dev, head='classic', drop_path_rate=0.0, test_cfg=None):
+    from vitpose_amd.builder import build_posenet
+    hc = dict(O.classic_head_cfg(64) if head == 'classic' else O.simple_head_cfg(64))
+    hc.update(type='TopdownHeatmapSimpleHead', loss_keypoint=dict(LOSS))
+    bc = dict(TOY, type='ViT', drop_path_rate=drop_path_rate)
+    m = build_posenet(dict(type='TopDown', backbone=bc, keypoint_head=hc, train_cfg=dict(),
+                           test_cfg=test_cfg or dict(flip_test=True, post_process='default', shift_heatmap=False)))
+    ohc = O.classic_head_cfg(64) if head == 'classic' else O.simple_head_cfg(64)
+    bb, hd = O.synth_vit_weights(TOY, seed=1), O.synth_head_weights(ohc, seed=2)
+    sd = {'backbone.' + k: v for k, v in bb.items()}
+    sd.update({'keypoint_head.' + k: v for k, v in hd.items()})
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all('num_batches_tracked' in k for k in missing)
+    return m.to(dev), bb, hd, ohc
+
+
+def test_head_shapes_of_the_reference_unit_test(dev):
+    from vitpose_amd.models import TopdownHeatmapSimpleHead
+    x = torch.rand(1, 512, 32, 32, device=dev)
+    head = TopdownHeatmapSimpleHead(out_channels=3, in_channels=512, loss_keypoint=LOSS).to(dev)
+    head.init_weights()
+    with torch.no_grad():
+        assert head(x).shape == torch.Size([1, 3, 256, 256])
+    head = TopdownHeatmapSimpleHead(out_channels=3, in_channels=512, num_deconv_layers=0, loss_keypoint=LOSS).to(dev)
+    with torch.no_grad():
+        assert head(x).shape == torch.Size([1, 3, 32, 32])
+        assert head([x]).shape == torch.Size([1, 3, 32, 32])
+
+
+def test_joints_mse_loss_known_answers(dev):
+    """tests/test_losses/test_top_down_losses.py:27-43."""
+    from vitpose_amd.builder import build_loss
+    loss = build_loss(dict(type='JointsMSELoss', use_target_weight=True))
+    fake_pred = torch.zeros((1, 3, 64, 64), device=dev)
+    fake_label = torch.zeros((1, 3, 64, 64), device=dev)
+    w = torch.tensor([1., 0., 1.], device=dev).reshape(1, 3, 1)
+    assert torch.allclose(loss(fake_pred, fake_label, w), torch.tensor(0., device=dev))
+    fake_pred = torch.ones((1, 3, 64, 64), device=dev)
+    assert torch.allclose(loss(fake_pred, fake_label, torch.ones(1, 3, 1, device=dev)), torch.tensor(1., device=dev))
+    fake_pred = torch.zeros((1, 2, 64, 64), device=dev)
+    fake_pred[0, 0] += 1
+    fake_label = torch.zeros((1, 2, 64, 64), device=dev)
+    assert torch.allclose(loss(fake_pred, fake_label, torch.ones(1, 2, 1, device=dev)), torch.tensor(0.5, device=dev))
+    # gradient against autograd of the oracle
+    g = torch.Generator().manual_seed(3)
+    o, t = torch.randn(3, 17, 64, 48, generator=g), torch.rand(3, 17, 64, 48, generator=g)
+    tw = (torch.rand(3, 17, 1, generator=g) > 0.3).float()
+    od = o.to(dev).requires_grad_()
+    l = loss(od, t.to(dev), tw.to(dev))
+    (2.5 * l).backward()
+    oc = o.clone().requires_grad_()
+    lr = O.joints_mse_loss(oc, t, tw)
+    (2.5 * lr).backward()
+    assert abs(l.item() - lr.item()) < 1e-5 * abs(lr.item())
+    torch.testing.assert_close(od.grad.cpu(), oc.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_pck_accuracy_known_answers(dev):
+    """tests/test_evaluation/test_top_down_eval.py:11-26 with the arg-max on the device."""
+    from vitpose_amd.models import pose_pck_accuracy_device
+    out = np.zeros((1, 5, 64, 64), dtype=np.float32)
+    tgt = np.zeros_like(out)
+    thr = np.full((1, 2), 10, dtype=np.float32)  # noqa: F841  (the reference normalises by [H, W] here too)
+    out[0, 0, 0, 0] = out[0, 1, 0, 0] = out[0, 2, 0, 1] = out[0, 3, 0, 1] = out[0, 4, 0, 0] = 1
+    tgt[0, 0, 0, 0] = tgt[0, 1, 0, 0] = tgt[0, 2, 0, 0] = tgt[0, 3, 0, 0] = tgt[0, 4, 63, 63] = 1
+    mask = np.array([[True, True, False, False, False]])
+    acc, avg, cnt = pose_pck_accuracy_device(torch.from_numpy(out).to(dev), torch.from_numpy(tgt).to(dev), mask, 0.5)
+    np.testing.assert_allclose(acc, np.array([1.0, 1.0, -1.0, -1.0, -1.0]), atol=1e-4)
+    assert abs(avg - 1.0) < 1e-4 and cnt == 2
+    g = torch.Generator().manual_seed(50)
+    o, t = torch.randn(3, 17, 64, 48, generator=g), torch.rand(3, 17, 64, 48, generator=g)
+    w = (torch.rand(3, 17, 1, generator=g) > 0.3).float()
+    m = w.numpy().squeeze(-1) > 0
+    acc, avg, cnt = pose_pck_accuracy_device(o.to(dev), t.to(dev), m)
+    racc, ravg, rcnt = O.pck_accuracy(o.numpy(), t.numpy(), m)
+    np.testing.assert_allclose(acc, racc)
+    assert avg == pytest.approx(ravg) and cnt == rcnt
+
+
+def test_vit_module_forward_backward_vs_oracle(dev):
+    from vitpose_amd.models import ViT
+    vit = ViT(**TOY)
+    bb = O.synth_vit_weights(TOY, seed=1)
+    vit.load_state_dict(bb)
+    vit = vit.to(dev).train()
+    assert vit.pos_embed.data_ptr() == vit._store.view('pos_embed').data_ptr()   # parameters alias the flat store
+    img, _, _ = O.synth_batch(2, seed=3)
+    out = vit(img.to(dev))
+    assert out.shape == (2, 64, 16, 12) and out.requires_grad
+    g = torch.Generator().manual_seed(4)
+    cot = torch.randn(2, 64, 16, 12, generator=g)
+    (out * cot.to(dev)).sum().backward()
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    ref = O.vit_forward(bbr, img, TOY)
+    (ref * cot).sum().backward()
+    assert rel(out, ref) < 2e-2
+    for n, p in vit.named_parameters():
+        assert p.grad is not None, n
+        assert rel(p.grad, bbr[n].grad) < 6e-2, (n, rel(p.grad, bbr[n].grad))
+    # a second backward without zero_grad accumulates, as autograd does
+    out2 = vit(img.to(dev))
+    (out2 * cot.to(dev)).sum().backward()
+    assert rel(vit.blocks[0].attn.qkv.weight.grad, 2 * bbr['blocks.0.attn.qkv.weight'].grad) < 6e-2
+    # eval / no_grad path and an in-place weight change (picked up through the version counters)
+    vit.eval()
+    with torch.no_grad():
+        o1 = vit(img.to(dev))
+        vit.last_norm.bias.add_(1.0)
+        o2 = vit(img.to(dev))
+    assert rel(o1, ref) < 2e-2 and abs((o2 - o1).mean().item() - 1.0) < 1e-2
+
+
+@pytest.mark.parametrize('kind', ['classic', 'simple'])
+def test_head_module_forward_backward_vs_oracle(dev, kind):
+    from vitpose_amd.models import TopdownHeatmapSimpleHead
+    hc = O.classic_head_cfg(64) if kind == 'classic' else O.simple_head_cfg(64)
+    head = TopdownHeatmapSimpleHead(loss_keypoint=dict(LOSS), **hc)
+    hd = O.synth_head_weights(hc, seed=2)
+    head.load_state_dict(hd, strict=False)
+    head = head.to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 16, 12, generator=g)
+    _, target, tw = O.synth_batch(2, seed=6)
+    xd = x.to(dev).requires_grad_()
+    out = head(xd)
+    losses = head.get_loss(out, target.to(dev), tw.to(dev))
+    losses['heatmap_loss'].backward()
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    xr = x.clone().requires_grad_()
+    ref = O.head_forward(hdr, xr, hc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert rel(out, ref) < 2e-2 and abs(losses['heatmap_loss'].item() - rl.item()) < 2e-2 * rl.item()
+    # the input gradient of the deconv head passes two BatchNorm backward passes, whose mean
+    # subtractions cancel most of the signal and so amplify the bf16 rounding of dz (7e-2 measured)
+    assert rel(xd.grad, xr.grad) < (0.12 if kind == 'classic' else 6e-2)
+    for n, p in head.named_parameters():
+        assert rel(p.grad, hdr[n].grad) < (0.1 if kind == 'classic' else 6e-2), n
+    if kind == 'classic':   # running statistics updated in the module's own buffers
+        assert rel(head.deconv_layers[1].running_mean, hdr['deconv_layers.1.running_mean']) < 2e-2
+        assert int(head.deconv_layers[1].num_batches_tracked) == 1
+    acc = head.get_accuracy(out, target.to(dev), tw.to(dev))
+    ref_acc = O.pck_accuracy(out.detach().cpu().numpy(), target.numpy(), tw.numpy().squeeze(-1) > 0)[1]
+    assert acc['acc_pose'] == pytest.approx(ref_acc)
+
+
+@pytest.mark.parametrize('kind', ['classic', 'simple'])
+def test_topdown_fused_train_step_vs_oracle(dev, kind):
+    model, bb, hd, ohc = toy_model(dev, kind)
+    assert model._engine is not None
+    assert model.backbone.pos_embed.data_ptr() == model._engine.store.view('backbone.pos_embed').data_ptr()
+    model.train()
+    img, target, tw = O.synth_batch(2, seed=3)
+    out = model.train_step(dict(img=img.to(dev), target=target.to(dev), target_weight=tw.to(dev), img_metas=None), None)
+    assert set(out) == {'loss', 'log_vars', 'num_samples'} and out['num_samples'] == 2
+    assert set(out['log_vars']) == {'heatmap_loss', 'acc_pose', 'loss'}
+    out['loss'].backward()
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), ohc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert abs(out['log_vars']['loss'] - rl.item()) < 2e-2 * rl.item()
+    ref_acc = O.pck_accuracy(ref.detach().numpy(), target.numpy(), tw.numpy().squeeze(-1) > 0)[1]
+    assert abs(out['log_vars']['acc_pose'] - ref_acc) < 0.05
+    worst = 0.0
+    for n, p in model.named_parameters():
+        r = (bbr[n[9:]] if n.startswith('backbone.') else hdr[n[14:]]).grad
+        assert p.grad is not None, n
+        worst = max(worst, rel(p.grad, r))
+    # classic head: two BatchNorm backward passes over a 2-image batch amplify bf16 rounding (9e-2 measured)
+    assert worst < (0.12 if kind == 'classic' else 8e-2), worst
+    # one fused layer-decay AdamW step through the config-shaped optimizer dict
+    opt = model.build_optimizer(dict(type='AdamW', lr=1e-3, betas=(0.9, 0.999), weight_decay=0.1,
+                                     constructor='LayerDecayOptimizerConstructor',
+                                     paramwise_cfg=dict(num_layers=2, layer_decay_rate=0.75)),
+                                grad_clip=dict(max_norm=1., norm_type=2))
+    before = model.backbone.blocks[1].mlp.fc2.weight.detach().clone()
+    opt.step()
+    opt.zero_grad()
+    delta = (model.backbone.blocks[1].mlp.fc2.weight.detach() - before).abs().max().item()
+    assert 0 < delta <= 1.1e-3 and model.backbone.pos_embed.grad is None
+
+
+def test_topdown_forward_test_flip_and_decode(dev, golden_dir):
+    """forward_test with flip_test=True (top_down.py:163-200) on ViTPose-S classic against the golden
+    produced by the reference source (average of the plain and flipped-back passes)."""
+    from vitpose_amd.builder import build_posenet
+    g3 = np.load(os.path.join(golden_dir, 'vitpose_s_classic_fliptest.npz'))
+    vcfg, hc = O.vit_cfg('S'), O.classic_head_cfg(384)
+    m = build_posenet(dict(type='TopDown', backbone=dict(vcfg, type='ViT'),
+                           keypoint_head=dict(hc, type='TopdownHeatmapSimpleHead', loss_keypoint=dict(LOSS)),
+                           train_cfg=dict(), test_cfg=dict(flip_test=True, post_process='default',
+                                                           shift_heatmap=False, use_udp=False)))
+    sd = {'backbone.' + k: v for k, v in O.synth_vit_weights(vcfg, seed=20).items()}
+    sd.update({'keypoint_head.' + k: v for k, v in O.synth_head_weights(hc, seed=21).items()})
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    img, _, _ = O.synth_batch(2, seed=22)
+    metas = [dict(center=np.array([100., 120.]), scale=np.array([1.2, 1.6]), image_file=f'{i}.jpg', bbox_id=i,
+                  flip_pairs=PAIRS, bbox_score=0.9) for i in range(2)]
+    res = m(img=img.to(dev), img_metas=metas, return_loss=False, return_heatmap=True)
+    assert set(res) == {'preds', 'boxes', 'image_paths', 'bbox_ids', 'output_heatmap'}
+    assert rel(res['output_heatmap'], g3['heat']) < 3e-2
+    assert res['preds'].shape == (2, 17, 3) and res['boxes'].shape == (2, 6) and res['bbox_ids'] == [0, 1]
+    # decode is host arithmetic on the heat maps: identical to the reference recipe applied to OUR maps
+    hm = res['output_heatmap']
+    idx = hm.reshape(2, 17, -1).argmax(2)
+    np.testing.assert_allclose(res['preds'][:, :, 2], hm.reshape(2, 17, -1).max(2), rtol=1e-6)
+    px = (idx % 48).astype(np.float32)
+    x_img = res['preds'][:, :, 0]
+    sx = 1.2 * 200 / 48
+    assert np.all(np.abs((x_img - (100. - 1.2 * 100)) / sx - px) <= 0.2501)
+    # forward_dummy = heat maps of one plain pass
+    with torch.no_grad():
+        d = m.forward_dummy(img.to(dev))
+    g1 = np.load(os.path.join(golden_dir, 'vitpose_s_classic_eval.npz'))
+    assert rel(d, g1['heat']) < 3e-2
+
+
+def test_torch_optimizer_and_state_dict_roundtrip(dev):
+    """The parameters are ordinary nn.Parameters: a stock torch optimizer can step them (its in-place
+    update is picked up by the next forward), and state_dict()/load_state_dict() round-trip."""
+    model, bb, hd, _ = toy_model(dev, 'classic')
+    model.train()
+    img, target, tw = O.synth_batch(2, seed=3)
+    opt = torch.optim.SGD(model.parameters(), lr=0.02)
+    batch = dict(img=img.to(dev), target=target.to(dev), target_weight=tw.to(dev), img_metas=None)
+    l0 = model.train_step(batch, None)
+    l0['loss'].backward()
+    opt.step()
+    opt.zero_grad()
+    l1 = model.train_step(batch, None)
+    assert l1['log_vars']['loss'] < l0['log_vars']['loss']
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert sd['backbone.pos_embed'].shape == (1, 193, 64)
+    model2, _, _, _ = toy_model(dev, 'classic')
+    model2.load_state_dict(sd)
+    model.eval(), model2.eval()
+    with torch.no_grad():
+        a, b = model.forward_dummy(img.to(dev)), model2.forward_dummy(img.to(dev))
+    assert torch.equal(a, b)

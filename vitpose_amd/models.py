@@ -1,0 +1,1090 @@
+"""The reference's model classes for the ViTPose hot path, re-implemented over the HIP plans:
+
+    ViT                        mmpose/models/backbones/vit.py:200-341
+    TopdownHeatmapSimpleHead   mmpose/models/heads/topdown_heatmap_simple_head.py:16-350
+    JointsMSELoss              mmpose/models/losses/mse_loss.py:9-44
+    TopDown                    mmpose/models/detectors/top_down.py:22-218 (+ detectors/base.py:38-126)
+
+Same registry names, constructor keywords, state-dict keys, exceptions and call contract, so the
+reference's `model = dict(type='TopDown', backbone=dict(type='ViT', ...), ...)` configs build
+them unchanged.  The torch sub-modules (nn.Linear, nn.LayerNorm, nn.Conv2d, nn.ConvTranspose2d,
+nn.BatchNorm2d) are PARAMETER HOLDERS only: they give the reference's parameter names, shapes
+and default initialisation, and are never called.  All arithmetic runs in the gfx950 kernels of
+libvitpose_hip.so; there is no CPU execution path (forward on a CPU tensor raises).
+
+Storage.  On a HIP device every module keeps its parameters in one flat f32 buffer
+(engine.ParamStore: master weights + bf16 mirror + gradient buffer); the nn.Parameters are views
+into it, and after a backward pass `param.grad` is a view into the flat gradient buffer.  A
+TopDown that holds a native backbone and head fuses both into ONE store and one launch plan
+(the token-major backbone output feeds the head directly, the loss is fused into the head).
+"""
+import warnings
+from collections import OrderedDict
+from functools import partial
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib
+from .builder import BACKBONES, HEADS, LOSSES, POSENETS, build_backbone, build_head, build_loss, build_neck
+from .engine import ParamStore, VitRunner, Workspace
+from .head_engine import KPAD, HeadRunner
+from .plan import Plan
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def _need_hip(t: torch.Tensor, what: str):
+    if t.device.type != 'cuda':
+        raise RuntimeError(f'{what} runs on an MI355X (HIP device) only; there is no CPU path '
+                           f'(got a tensor on {t.device})')
+    _lib.lib()
+
+
+def _param_versions(params):
+    return sum(p._version for p in params)
+
+
+class _Holder(nn.Module):
+    """A sub-module that only names parameters; the enclosing HIP module computes."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(f'{type(self).__name__} is evaluated inside the HIP plan of its parent module')
+
+
+class _FlatBound(nn.Module):
+    """Mixin: keeps the module's parameters (and float buffers) as views of one ParamStore while
+    they live on a HIP device, and re-creates the store whenever the module is moved."""
+    _owned = False      # True while a TopDown has fused this module's parameters into its own store
+    _store: Optional[ParamStore] = None
+    _prefix = ''        # this module's name inside the owner's store ('backbone.' / 'keypoint_head.')
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if not self._owned:
+            self._bind()
+        return out
+
+    def _bind(self):
+        params = list(self.named_parameters())
+        self._store, self._runners, self._plans = None, {}, {}
+        if not params or params[0][1].device.type != 'cuda':
+            return
+        st = ParamStore([(n, tuple(p.shape)) for n, p in params], params[0][1].device)
+        for n, p in params:
+            st.view(n).copy_(p.data)
+            p.data = st.view(n)
+            p.grad = None
+        self._store = st
+        self._seen_version = None
+
+    def _grad_slice(self):
+        """This module's part of the flat gradient buffer (its parameters are contiguous there)."""
+        st = self._store
+        names = [self._prefix + n for n, _ in self.named_parameters()]
+        lo = min(st.offsets[n] for n in names)
+        hi = max(st.offsets[n] + st.gview(n).numel() for n in names)
+        return st.grad[lo:hi]
+
+    def _publish_grads(self, stash):
+        """After a backward plan wrote fresh gradients into the flat buffer: expose them as
+        `.grad` views (adding what was there before, as autograd would)."""
+        st = self._store
+        if stash is not None:
+            self._grad_slice().add_(stash)
+        for n, p in self.named_parameters():
+            if p.requires_grad:
+                gv = st.gview(self._prefix + n)
+                if p.grad is None or p.grad.data_ptr() == gv.data_ptr():
+                    p.grad = gv
+                else:           # a foreign .grad tensor: accumulate into it
+                    p.grad.add_(gv)
+
+    def _stash_live_grads(self):
+        """Gradients of an earlier backward still held in the flat buffer (no zero_grad since)."""
+        st = self._store
+        for n, p in self.named_parameters():
+            if p.grad is not None and p.grad.data_ptr() == st.gview(self._prefix + n).data_ptr():
+                return self._grad_slice().clone()
+        return None
+
+
+# =====================================================================================
+# backbone
+# =====================================================================================
+class DropPath(_Holder):
+    """Stochastic depth per sample (vit.py:48-59); the rate is applied by the HIP epilogues."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def extra_repr(self):
+        return 'p={}'.format(self.drop_prob)
+
+
+class Mlp(_Holder):
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(_Holder):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads, self.dim = num_heads, dim
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, head_dim * num_heads * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(head_dim * num_heads, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class Block(_Holder):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), drop=drop)
+
+
+class PatchEmbed(_Holder):
+    """vit.py:143-165: Conv2d(in, E, patch, stride = patch // ratio, padding = 4 + 2*(ratio//2 - 1))."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, ratio=1):
+        super().__init__()
+        img_size, patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0]) * (ratio ** 2)
+        self.patch_shape = (int(img_size[0] // patch_size[0] * ratio), int(img_size[1] // patch_size[1] * ratio))
+        self.origin_patch_shape = (int(img_size[0] // patch_size[0]), int(img_size[1] // patch_size[1]))
+        self.img_size, self.patch_size = img_size, patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=(patch_size[0] // ratio),
+                              padding=4 + 2 * (ratio // 2 - 1))
+
+
+class _ViTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, img, *params):
+        ctx.mod, ctx.B = mod, img.shape[0]
+        return mod._run(img, keep=True)
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        ctx.mod._run_backward(dfeat, ctx.B)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+@BACKBONES.register_module()
+class ViT(_FlatBound):
+    """Plain ViT backbone of ViTPose (vit.py:200-341) on the HIP kernels."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=80, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., hybrid_backbone=None, norm_layer=None, use_checkpoint=False,
+                 frozen_stages=-1, ratio=1, last_norm=True, patch_padding='pad', freeze_attn=False,
+                 freeze_ffn=False):
+        super().__init__()
+        if hybrid_backbone is not None:
+            raise NotImplementedError('hybrid_backbone (CNN patch embedding) is outside the HIP path')
+        if norm_layer is not None:
+            raise NotImplementedError('the HIP path implements LayerNorm(eps=1e-6), the reference default')
+        if drop_rate or attn_drop_rate:
+            raise NotImplementedError('drop_rate / attn_drop_rate > 0 (all ViTPose configs use 0)')
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.frozen_stages = frozen_stages
+        self.use_checkpoint = use_checkpoint   # accepted; every activation fits HBM, nothing is recomputed
+        self.patch_padding = patch_padding
+        self.freeze_attn, self.freeze_ffn = freeze_attn, freeze_ffn
+        self.depth = depth
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, ratio)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_rate, attn_drop_rate, dpr[i], norm_layer)
+            for i in range(depth)])
+        self.last_norm = norm_layer(embed_dim) if last_norm else nn.Identity()
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        self._cfg = dict(img_size=to_2tuple(img_size), patch_size=to_2tuple(patch_size)[0], in_chans=in_chans,
+                         embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                         qkv_bias=qkv_bias, qk_scale=qk_scale, ratio=ratio, last_norm=last_norm,
+                         drop_path_rate=drop_path_rate)
+        self._freeze_stages()
+
+    # ---- reference API ----
+    def _freeze_stages(self):
+        """vit.py:249-284."""
+        def freeze(m):
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+        if self.frozen_stages >= 0:
+            freeze(self.patch_embed)
+        for i in range(1, self.frozen_stages + 1):
+            freeze(self.blocks[i])
+        if self.freeze_attn:
+            for blk in self.blocks:
+                freeze(blk.attn)
+                freeze(blk.norm1)
+        if self.freeze_ffn:
+            self.pos_embed.requires_grad = False
+            freeze(self.patch_embed)
+            for blk in self.blocks:
+                freeze(blk.mlp)
+                freeze(blk.norm2)
+
+    def init_weights(self, pretrained=None):
+        """vit.py:286-304 / base_backbone.py:17-34: a str loads a checkpoint, None self-initialises."""
+        if isinstance(pretrained, str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False, patch_padding=self.patch_padding)
+        elif pretrained is None:
+            def _init(m):
+                if isinstance(m, nn.Linear):
+                    nn.init.trunc_normal_(m.weight, std=.02)
+                    if m.bias is not None:
+                        nn.init.constant_(m.bias, 0)
+                elif isinstance(m, nn.LayerNorm):
+                    nn.init.constant_(m.bias, 0)
+                    nn.init.constant_(m.weight, 1.0)
+            self.apply(_init)
+        else:
+            raise TypeError('pretrained must be a str or None.'
+                            f' But received {type(pretrained)}.')
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        return self
+
+    # ---- HIP execution ----
+    def _runner(self):
+        r = self._runners.get('vit')
+        if r is None:
+            r = self._runners['vit'] = VitRunner(self._cfg, self._store, self._prefix)
+            prep = Plan()
+            prep.cast_f32_bf16(self._store.data, self._store.half, self._store.numel)
+            self._runners['prep'] = prep
+        return r
+
+    def _refresh(self):
+        v = _param_versions(self.parameters())
+        if v != self._seen_version:
+            self._runners['prep'].run()
+            self._runners['vit'].refresh_derived()
+            self._seen_version = v
+
+    def _plan(self, B, keep):
+        key = (B, keep)
+        if key not in self._plans:
+            vr = self._runner()
+            ws = self._runners.setdefault(('ws', keep), Workspace(self._store.device))
+            H, W = vr.img_hw
+            io = dict(img=ws.f32('img', B, vr.C, H, W), tok=ws.f32('tok_out', B * vr.T, vr.E),
+                      out=ws.f32('feat_nchw', B, vr.E, vr.Hp, vr.Wp))
+            fwd = Plan()
+            dp = None
+            if keep:
+                dp = io['dp'] = ws.f32('dp', vr.depth, 2, B)
+                dp.fill_(1.0)
+            feat = vr.record_forward(fwd, ws, io['img'], B, training=keep, dp=dp, tokens_f32=io['tok'])
+            # token-major [B][T][E] -> NCHW [B][E][Hp][Wp] (vit.py:330)
+            fwd.strided_cast(io['tok'], io['out'], (B, vr.E, vr.T, 1), (vr.T * vr.E, 1, vr.E, 0))
+            bwd = None
+            if keep:
+                io['dfeat'] = ws.f32('dfeat_nchw', B, vr.E, vr.Hp, vr.Wp)
+                dcl = ws.bf16('dfeat_cl', B * vr.T, vr.E)
+                bwd = Plan()
+                bwd.memset0(self._grad_slice())
+                bwd.nchw_to_cl(io['dfeat'], dcl, B, vr.E, vr.T, vr.E)
+                vr.record_backward(bwd, ws, dcl, B, dp=dp)
+            self._plans[key] = (fwd, bwd, io)
+        return self._plans[key]
+
+    def _run(self, img, keep):
+        B, C, H, W = img.shape
+        vr = self._runner()
+        if (H, W) != tuple(vr.img_hw) or C != vr.C:
+            raise ValueError(f'input {tuple(img.shape)} does not match img_size {vr.img_hw} / in_chans {vr.C}')
+        self._refresh()
+        fwd, _, io = self._plan(B, keep)
+        io['img'].copy_(img)
+        if keep:
+            if self.training and max(vr.dp_rates) > 0:
+                vr.sample_drop_path(io['dp'])
+            else:
+                io['dp'].fill_(1.0)
+        fwd.run()
+        return io['out'].clone()
+
+    def _run_backward(self, dfeat, B):
+        _, bwd, io = self._plan(B, True)
+        stash = self._stash_live_grads()
+        io['dfeat'].copy_(dfeat)
+        bwd.run()
+        self._publish_grads(stash)
+
+    def forward_features(self, x):
+        _need_hip(x, 'ViT.forward')
+        if self._store is None:
+            raise RuntimeError('move the module to the HIP device first (model.cuda())')
+        params = [p for p in self.parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _ViTFunction.apply(self, x.float(), *params)
+        return self._run(x.float(), keep=False)
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+# =====================================================================================
+# loss
+# =====================================================================================
+class _MSEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target, tw, loss_weight):
+        B, K = output.shape[:2]
+        HW = output[0, 0].numel()
+        out = output.contiguous().float()
+        loss = torch.zeros(1, dtype=torch.float32, device=out.device)
+        dpred = torch.empty_like(out) if output.requires_grad else None
+        p = Plan()
+        p.mse_loss_nchw(out, target.contiguous().float(), None if tw is None else tw.reshape(B, K).contiguous().float(),
+                        loss, dpred, B, K, HW, float(loss_weight))
+        p.run()
+        ctx.dpred = dpred
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.dpred * g if ctx.dpred is not None else None), None, None, None
+
+
+@LOSSES.register_module()
+class JointsMSELoss(nn.Module):
+    """mse_loss.py:9-44: mean over joints of the MSE between (weighted) heat maps."""
+
+    def __init__(self, use_target_weight=False, loss_weight=1.):
+        super().__init__()
+        self.use_target_weight = use_target_weight
+        self.loss_weight = loss_weight
+
+    def forward(self, output, target, target_weight):
+        _need_hip(output, 'JointsMSELoss.forward')
+        return _MSEFunction.apply(output, target, target_weight if self.use_target_weight else None,
+                                  self.loss_weight)
+
+
+# =====================================================================================
+# head
+# =====================================================================================
+def flip_back(output_flipped, flip_pairs, target_type='GaussianHeatmap'):
+    """core/post_processing/post_transforms.py:110-147 on host arrays (the reference consumes
+    heat maps as numpy here): swap the mirrored joints' maps, reverse the width axis."""
+    assert output_flipped.ndim == 4, 'output_flipped should be [batch_size, num_keypoints, height, width]'
+    shape_ori = output_flipped.shape
+    channels = 1
+    if target_type.lower() == 'CombinedTarget'.lower():
+        channels = 3
+        output_flipped[:, 1::3, ...] = -output_flipped[:, 1::3, ...]
+    output_flipped = output_flipped.reshape(shape_ori[0], -1, channels, shape_ori[2], shape_ori[3])
+    back = output_flipped.copy()
+    for left, right in flip_pairs:
+        back[:, left, ...] = output_flipped[:, right, ...]
+        back[:, right, ...] = output_flipped[:, left, ...]
+    return back.reshape(shape_ori)[..., ::-1]
+
+
+def transform_preds(coords, center, scale, output_size, use_udp=False):
+    """core/post_processing/post_transforms.py:150-194."""
+    assert coords.shape[1] in (2, 4, 5) and len(center) == 2 and len(scale) == 2 and len(output_size) == 2
+    scale = scale * 200.0
+    if use_udp:
+        sx, sy = scale[0] / (output_size[0] - 1.0), scale[1] / (output_size[1] - 1.0)
+    else:
+        sx, sy = scale[0] / output_size[0], scale[1] / output_size[1]
+    out = np.ones_like(coords)
+    out[:, 0] = coords[:, 0] * sx + center[0] - scale[0] * 0.5
+    out[:, 1] = coords[:, 1] * sy + center[1] - scale[1] * 0.5
+    return out
+
+
+def _get_max_preds(heatmaps):
+    """core/evaluation/top_down_eval.py:63-95 on a host array."""
+    assert isinstance(heatmaps, np.ndarray), 'heatmaps should be numpy.ndarray'
+    assert heatmaps.ndim == 4, 'batch_images should be 4-ndim'
+    N, K, _, W = heatmaps.shape
+    flat = heatmaps.reshape((N, K, -1))
+    idx = np.argmax(flat, 2).reshape((N, K, 1))
+    maxvals = np.amax(flat, 2).reshape((N, K, 1))
+    preds = np.tile(idx, (1, 1, 2)).astype(np.float32)
+    preds[:, :, 0] = preds[:, :, 0] % W
+    preds[:, :, 1] = preds[:, :, 1] // W
+    preds = np.where(np.tile(maxvals, (1, 1, 2)) > 0.0, preds, -1)
+    return preds, maxvals
+
+
+def keypoints_from_heatmaps(heatmaps, center, scale, unbiased=False, post_process='default', kernel=11,
+                            valid_radius_factor=0.0546875, use_udp=False, target_type='GaussianHeatmap'):
+    """core/evaluation/top_down_eval.py:474-622 for post_process None / 'default' without UDP
+    (arg-max, quarter-pixel shift towards the higher neighbour, map back to the image).
+    The DARK / UDP / megvii refinements need cv2.GaussianBlur and are not covered."""
+    if unbiased or use_udp or post_process not in (None, 'default'):
+        raise NotImplementedError('decode covers post_process None / "default" without UDP / DARK')
+    heatmaps = heatmaps.copy()
+    N, K, H, W = heatmaps.shape
+    preds, maxvals = _get_max_preds(heatmaps)
+    if post_process is not None:
+        for n in range(N):
+            for k in range(K):
+                hm = heatmaps[n][k]
+                px, py = int(preds[n][k][0]), int(preds[n][k][1])
+                if 1 < px < W - 1 and 1 < py < H - 1:
+                    diff = np.array([hm[py][px + 1] - hm[py][px - 1], hm[py + 1][px] - hm[py - 1][px]])
+                    preds[n][k] += np.sign(diff) * .25
+    for i in range(N):
+        preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H], use_udp=use_udp)
+    return preds, maxvals
+
+
+def pose_pck_accuracy_device(output, target, mask, thr=0.05):
+    """pose_pck_accuracy (core/evaluation/top_down_eval.py:136-176) with the two arg-max passes
+    (`_get_max_preds`, :63-95) on the device: only [N, K] indices and maxima cross to the host,
+    not the 2 x N*K*H*W heat maps the reference copies every iteration.
+    Returns (acc [K], avg_acc, cnt) like the reference."""
+    N, K, H, W = output.shape
+    if K == 0:
+        return None, 0, 0
+    idx = torch.empty(2, N * K, dtype=torch.int32, device=output.device)
+    val = torch.empty(2, N * K, dtype=torch.float32, device=output.device)
+    p = Plan()
+    p.argmax_rows(output.detach().contiguous().float(), N * K, H * W, idx[0], val[0])
+    p.argmax_rows(target.detach().contiguous().float(), N * K, H * W, idx[1], val[1])
+    p.run()
+    idx_h, val_h = idx.cpu().numpy().astype(np.int64), val.cpu().numpy()
+    coords = []
+    for i in range(2):
+        xy = np.stack([idx_h[i] % W, idx_h[i] // W], -1).astype(np.float32).reshape(N, K, 2)
+        coords.append(np.where((val_h[i] > 0.0).reshape(N, K, 1), xy, -1))
+    pred, gt = coords
+    norm = np.tile(np.array([[H, W]], dtype=np.float32), (N, 1))
+    mask = np.asarray(mask).copy()
+    # _calc_distances (:10-54): joints whose normaliser is <= 0 are masked out
+    mask[np.where((norm <= 0).sum(1))[0], :] = False
+    dist = np.full((N, K), -1, dtype=np.float32)
+    norm_c = norm.copy()
+    norm_c[np.where(norm_c <= 0)] = 1e6
+    d = np.linalg.norm((pred - gt) / norm_c[:, None, :], axis=-1)
+    dist[mask] = d[mask]
+    dist = dist.T
+    acc = np.array([((dk[dk != -1] < thr).sum() / (dk != -1).sum()) if (dk != -1).sum() > 0 else -1 for dk in dist])
+    valid = acc[acc >= 0]
+    cnt = len(valid)
+    return acc, (valid.mean() if cnt > 0 else 0), cnt
+
+
+class _HeadFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        ctx.mod, ctx.shape = mod, tuple(x.shape)
+        return mod._run(x, keep=True)
+
+    @staticmethod
+    def backward(ctx, dheat):
+        dx = ctx.mod._run_backward(dheat, ctx.shape)
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+@HEADS.register_module()
+class TopdownHeatmapSimpleHead(_FlatBound):
+    """topdown_heatmap_simple_head.py:16-350: deconv x n + BN + ReLU + final conv ("classic"), or
+    ReLU + bilinear upsample + final conv ("simple decoder"), on the HIP kernels."""
+
+    def __init__(self, in_channels, out_channels, num_deconv_layers=3, num_deconv_filters=(256, 256, 256),
+                 num_deconv_kernels=(4, 4, 4), extra=None, in_index=0, input_transform=None, align_corners=False,
+                 loss_keypoint=None, train_cfg=None, test_cfg=None, upsample=0):
+        super().__init__()
+        self.in_channels = in_channels
+        self.loss = build_loss(loss_keypoint)
+        self.upsample = upsample
+        self.train_cfg = {} if train_cfg is None else train_cfg
+        self.test_cfg = {} if test_cfg is None else test_cfg
+        self.target_type = self.test_cfg.get('target_type', 'GaussianHeatmap')
+        self._init_inputs(in_channels, in_index, input_transform)
+        self.in_index = in_index
+        self.align_corners = align_corners
+        if extra is not None and not isinstance(extra, dict):
+            raise TypeError('extra should be dict or None.')
+        head_in = self.in_channels
+        if num_deconv_layers > 0:
+            self.deconv_layers = self._make_deconv_layer(num_deconv_layers, num_deconv_filters, num_deconv_kernels)
+        elif num_deconv_layers == 0:
+            self.deconv_layers = nn.Identity()
+        else:
+            raise ValueError(f'num_deconv_layers ({num_deconv_layers}) should >= 0.')
+        identity_final_layer = False
+        if extra is not None and 'final_conv_kernel' in extra:
+            assert extra['final_conv_kernel'] in [0, 1, 3]
+            if extra['final_conv_kernel'] == 3:
+                padding = 1
+            elif extra['final_conv_kernel'] == 1:
+                padding = 0
+            else:
+                identity_final_layer = True
+            kernel_size = extra['final_conv_kernel']
+        else:
+            kernel_size, padding = 1, 0
+        if identity_final_layer:
+            self.final_layer = nn.Identity()
+        else:
+            conv_channels = num_deconv_filters[-1] if num_deconv_layers > 0 else self.in_channels
+            layers = []
+            if extra is not None:
+                num_conv_layers = extra.get('num_conv_layers', 0)
+                num_conv_kernels = extra.get('num_conv_kernels', [1] * num_conv_layers)
+                for i in range(num_conv_layers):
+                    layers += [nn.Conv2d(conv_channels, conv_channels, num_conv_kernels[i], 1,
+                                         (num_conv_kernels[i] - 1) // 2),
+                               nn.BatchNorm2d(conv_channels), nn.ReLU(inplace=True)]
+            layers.append(nn.Conv2d(conv_channels, out_channels, kernel_size, 1, padding))
+            self.final_layer = nn.Sequential(*layers) if len(layers) > 1 else layers[0]
+        self._cfg = dict(in_channels=head_in, out_channels=out_channels, num_deconv_layers=num_deconv_layers,
+                         num_deconv_filters=tuple(num_deconv_filters), num_deconv_kernels=tuple(num_deconv_kernels),
+                         extra=dict(extra or {}), upsample=upsample, align_corners=align_corners)
+        self._cfg['extra'].setdefault('final_conv_kernel', 1)
+
+    # ---- reference API ----
+    def _init_inputs(self, in_channels, in_index, input_transform):
+        """topdown_heatmap_simple_head.py:229-267."""
+        if input_transform is not None:
+            assert input_transform in ['resize_concat', 'multiple_select']
+        self.input_transform = input_transform
+        self.in_index = in_index
+        if input_transform is not None:
+            assert isinstance(in_channels, (list, tuple))
+            assert isinstance(in_index, (list, tuple))
+            assert len(in_channels) == len(in_index)
+            self.in_channels = sum(in_channels) if input_transform == 'resize_concat' else in_channels
+        else:
+            assert isinstance(in_channels, int)
+            assert isinstance(in_index, int)
+            self.in_channels = in_channels
+
+    @staticmethod
+    def _get_deconv_cfg(deconv_kernel):
+        """topdown_heatmap_base_head.py:105-120."""
+        if deconv_kernel == 4:
+            return 4, 1, 0
+        if deconv_kernel == 3:
+            return 3, 1, 1
+        if deconv_kernel == 2:
+            return 2, 0, 0
+        raise ValueError(f'Not supported num_kernels ({deconv_kernel}).')
+
+    def _make_deconv_layer(self, num_layers, num_filters, num_kernels):
+        if num_layers != len(num_filters):
+            raise ValueError(f'num_layers({num_layers}) != length of num_filters({len(num_filters)})')
+        if num_layers != len(num_kernels):
+            raise ValueError(f'num_layers({num_layers}) != length of num_kernels({len(num_kernels)})')
+        layers = []
+        for i in range(num_layers):
+            kernel, padding, output_padding = self._get_deconv_cfg(num_kernels[i])
+            planes = num_filters[i]
+            layers += [nn.ConvTranspose2d(self.in_channels, planes, kernel, stride=2, padding=padding,
+                                          output_padding=output_padding, bias=False),
+                       nn.BatchNorm2d(planes), nn.ReLU(inplace=True)]
+            self.in_channels = planes
+        return nn.Sequential(*layers)
+
+    def init_weights(self):
+        """topdown_heatmap_simple_head.py:339-350."""
+        for _, m in self.deconv_layers.named_modules():
+            if isinstance(m, nn.ConvTranspose2d):
+                nn.init.normal_(m.weight, 0, 0.001)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for m in self.final_layer.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 0.001)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def get_loss(self, output, target, target_weight):
+        losses = dict()
+        assert not isinstance(self.loss, nn.Sequential)
+        assert target.dim() == 4 and target_weight.dim() == 3
+        losses['heatmap_loss'] = self.loss(output, target, target_weight)
+        return losses
+
+    def get_accuracy(self, output, target, target_weight):
+        accuracy = dict()
+        if self.target_type == 'GaussianHeatmap':
+            _, avg_acc, _ = pose_pck_accuracy_device(
+                output, target, target_weight.detach().cpu().numpy().squeeze(-1) > 0)
+            accuracy['acc_pose'] = float(avg_acc)
+        return accuracy
+
+    def inference_model(self, x, flip_pairs=None):
+        output = self.forward(x)
+        if flip_pairs is not None:
+            output_heatmap = flip_back(output.detach().cpu().numpy(), flip_pairs, target_type=self.target_type)
+            if self.test_cfg.get('shift_heatmap', False):
+                output_heatmap[:, :, :, 1:] = output_heatmap[:, :, :, :-1]
+        else:
+            output_heatmap = output.detach().cpu().numpy()
+        return output_heatmap
+
+    def decode(self, img_metas, output, **kwargs):
+        """topdown_heatmap_base_head.py:40-103."""
+        batch_size = len(img_metas)
+        bbox_ids = [] if 'bbox_id' in img_metas[0] else None
+        c = np.zeros((batch_size, 2), dtype=np.float32)
+        s = np.zeros((batch_size, 2), dtype=np.float32)
+        image_paths = []
+        score = np.ones(batch_size)
+        for i in range(batch_size):
+            c[i, :] = img_metas[i]['center']
+            s[i, :] = img_metas[i]['scale']
+            image_paths.append(img_metas[i]['image_file'])
+            if 'bbox_score' in img_metas[i]:
+                score[i] = np.array(img_metas[i]['bbox_score']).reshape(-1)[0]
+            if bbox_ids is not None:
+                bbox_ids.append(img_metas[i]['bbox_id'])
+        preds, maxvals = keypoints_from_heatmaps(
+            output, c, s, unbiased=self.test_cfg.get('unbiased_decoding', False),
+            post_process=self.test_cfg.get('post_process', 'default'), kernel=self.test_cfg.get('modulate_kernel', 11),
+            valid_radius_factor=self.test_cfg.get('valid_radius_factor', 0.0546875),
+            use_udp=self.test_cfg.get('use_udp', False), target_type=self.test_cfg.get('target_type', 'GaussianHeatmap'))
+        all_preds = np.zeros((batch_size, preds.shape[1], 3), dtype=np.float32)
+        all_boxes = np.zeros((batch_size, 6), dtype=np.float32)
+        all_preds[:, :, 0:2] = preds[:, :, 0:2]
+        all_preds[:, :, 2:3] = maxvals
+        all_boxes[:, 0:2] = c[:, 0:2]
+        all_boxes[:, 2:4] = s[:, 0:2]
+        all_boxes[:, 4] = np.prod(s * 200.0, axis=1)
+        all_boxes[:, 5] = score
+        return dict(preds=all_preds, boxes=all_boxes, image_paths=image_paths, bbox_ids=bbox_ids)
+
+    def _transform_inputs(self, inputs):
+        """topdown_heatmap_simple_head.py:269-304 (the ReLU + resize of a tensor input happens inside
+        the HIP plan; feature lists select `in_index`)."""
+        if not isinstance(inputs, list):
+            return inputs
+        if self.input_transform is not None:
+            raise NotImplementedError('resize_concat / multiple_select inputs are outside the HIP path')
+        return inputs[self.in_index]
+
+    # ---- HIP execution ----
+    def _bn_buffers(self):
+        return {self._prefix + n: b for n, b in self.named_buffers() if b.dtype == torch.float32}
+
+    def _runner(self, grid):
+        key = ('head', grid)
+        r = self._runners.get(key)
+        if r is None:
+            r = self._runners[key] = HeadRunner(self._cfg, self._store, self._bn_buffers(), grid, self._prefix)
+            prep = Plan()
+            prep.cast_f32_bf16(self._store.data, self._store.half, self._store.numel)
+            r.record_weight_prep(prep)
+            self._runners[('prep', grid)] = prep
+            self._seen_version = None
+        return r
+
+    def _plan(self, shape, keep):
+        B, C, H, W = shape
+        key = (shape, keep, self.training)
+        if key not in self._plans:
+            hr = self._runner((H, W))
+            ws = self._runners.setdefault(('ws', keep), Workspace(self._store.device))
+            io = dict(x=ws.f32('x_nchw', B, C, H, W), feat=ws.bf16('feat_cl', B * H * W, C),
+                      heat=ws.f32('heat', B, hr.K, *hr.out_grid))
+            fwd = Plan()
+            fwd.nchw_to_cl(io['x'], io['feat'], B, C, H * W, C)
+            hr.record_forward(fwd, ws, io['feat'], B, keep and self.training, io['heat'])
+            bwd = None
+            if keep:
+                if not self.training and hr.nl:
+                    raise NotImplementedError('backward through the deconv head in eval mode (running-stat BN)')
+                io['dheat'] = ws.f32('dheat_in', B, hr.K, *hr.out_grid)
+                io['dx'] = ws.f32('dx_nchw', B, C, H, W)
+                bwd = Plan()
+                bwd.memset0(self._grad_slice())
+                g = hr.record_backward_nchw(bwd, ws, io['feat'], io['dheat'], B)
+                bwd.strided_cast(g, io['dx'], (B, C, H * W, 1), (H * W * C, 1, C, 0))
+            self._plans[key] = (fwd, bwd, io)
+        return self._plans[key]
+
+    def _refresh(self, grid):
+        self._runner(grid)
+        v = _param_versions(self.parameters())
+        if v != self._seen_version:
+            self._runners[('prep', grid)].run()
+            self._seen_version = v
+
+    def _run(self, x, keep):
+        shape = tuple(x.shape)
+        if shape[1] != self._cfg['in_channels']:
+            raise ValueError(f'expected {self._cfg["in_channels"]} input channels, got {shape[1]}')
+        self._refresh(shape[2:])
+        fwd, _, io = self._plan(shape, keep)
+        io['x'].copy_(x)
+        fwd.run()
+        if keep and self.training:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                    m.num_batches_tracked += 1
+        return io['heat'].clone()
+
+    def _run_backward(self, dheat, shape):
+        _, bwd, io = self._plan(shape, True)
+        stash = self._stash_live_grads()
+        io['dheat'].copy_(dheat)
+        bwd.run()
+        self._publish_grads(stash)
+        return io['dx'].clone()
+
+    def forward(self, x):
+        x = self._transform_inputs(x)
+        _need_hip(x, 'TopdownHeatmapSimpleHead.forward')
+        if self._store is None:
+            raise RuntimeError('move the module to the HIP device first (model.cuda())')
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return _HeadFunction.apply(self, x.float(), *params)
+        return self._run(x.float(), keep=False)
+
+
+# =====================================================================================
+# detector
+# =====================================================================================
+class _FusedTrainFunction(torch.autograd.Function):
+    """forward = the forward half of the fused PoseEngine plan (backbone + head + loss), backward =
+    its backward half; gradients land in the flat buffer the parameters' .grad alias."""
+
+    @staticmethod
+    def forward(ctx, mod, img, target, tw, *params):
+        ctx.mod, ctx.B = mod, img.shape[0]
+        return mod._fused_forward(img, target, tw)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.mod._fused_backward(ctx.B, g)
+        return (None,) * len(ctx.needs_input_grad)
+
+
+@POSENETS.register_module()
+class TopDown(nn.Module):
+    """Top-down pose detector container (top_down.py:22-218, detectors/base.py:38-126)."""
+
+    def __init__(self, backbone, neck=None, keypoint_head=None, train_cfg=None, test_cfg=None, pretrained=None,
+                 loss_pose=None):
+        super().__init__()
+        self.fp16_enabled = False
+        self.backbone = build_backbone(backbone)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if neck is not None:
+            self.neck = build_neck(neck)
+        if keypoint_head is not None:
+            keypoint_head['train_cfg'] = train_cfg
+            keypoint_head['test_cfg'] = test_cfg
+            if 'loss_keypoint' not in keypoint_head and loss_pose is not None:
+                warnings.warn('`loss_pose` for TopDown is deprecated, use `loss_keypoint` for heads instead.',
+                              DeprecationWarning)
+                keypoint_head['loss_keypoint'] = loss_pose
+            self.keypoint_head = build_head(keypoint_head)
+        self._engine = None
+        self.init_weights(pretrained=pretrained)
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck')
+
+    @property
+    def with_keypoint(self):
+        return hasattr(self, 'keypoint_head')
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights(pretrained)
+        if self.with_neck:
+            self.neck.init_weights()
+        if self.with_keypoint:
+            self.keypoint_head.init_weights()
+
+    # ---- fused storage / plan ----
+    def _fusable(self):
+        return (isinstance(self.backbone, ViT) and not self.with_neck and self.with_keypoint and
+                isinstance(self.keypoint_head, TopdownHeatmapSimpleHead) and
+                isinstance(self.keypoint_head.loss, JointsMSELoss))
+
+    def _apply(self, fn, *a, **k):
+        if self._fusable():
+            self.backbone._owned = self.keypoint_head._owned = True
+        out = super()._apply(fn, *a, **k)
+        if self._fusable():
+            self._bind()
+        return out
+
+    def _bind(self):
+        from .pose_engine import PoseEngine
+        self._engine = None
+        bb, hd = self.backbone, self.keypoint_head
+        for m in (bb, hd):
+            m._store, m._runners, m._plans = None, {}, {}
+        dev = bb.pos_embed.device
+        bb._prefix = hd._prefix = ''
+        if dev.type != 'cuda':
+            bb._owned = hd._owned = False
+            return
+        try:
+            eng = PoseEngine(bb._cfg, hd._cfg, dev, loss_weight=hd.loss.loss_weight,
+                             use_target_weight=hd.loss.use_target_weight)
+        except NotImplementedError:
+            # a shape outside the fused plan's kernels: fall back to module-by-module HIP execution
+            bb._owned = hd._owned = False
+            bb._bind()
+            hd._bind()
+            return
+        st = eng.store
+        for n, p in self.named_parameters():
+            st.view(n).copy_(p.data)
+            p.data = st.view(n)
+            p.grad = None
+        for n, b in self.named_buffers():
+            if n in eng.buffers:
+                eng.buffers[n].copy_(b.data)
+                b.data = eng.buffers[n]
+        # the sub-modules run from the same store when called on their own
+        bb._store = hd._store = st
+        bb._prefix, hd._prefix = 'backbone.', 'keypoint_head.'
+        bb._seen_version = hd._seen_version = None
+        self._engine = eng
+        self._seen_version = None
+
+    def _refresh(self):
+        v = _param_versions(self.parameters())
+        if v != self._seen_version:
+            self._engine.refresh_weights()
+            self._seen_version = v
+
+    def _fused_forward(self, img, target, tw):
+        eng = self._engine
+        B = img.shape[0]
+        self._refresh()
+        plan, io = eng._train_plan(B)
+        io['img'].copy_(img)
+        io['target'].copy_(target)
+        io['tw'].copy_(tw.reshape(B, -1))
+        vr = eng.vit
+        if self.backbone.training and max(vr.dp_rates) > 0:
+            vr.sample_drop_path(io['dp'])
+        else:
+            io['dp'].fill_(1.0)
+        self._stash = self._stash_live()
+        plan.run(first=0, last=eng.n_fwd_calls)
+        if self.keypoint_head.training:
+            for m in self.keypoint_head.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.num_batches_tracked += 1
+        self._heat = io['heat']
+        return io['loss'].reshape(()).clone()
+
+    def _stash_live(self):
+        st = self._engine.store
+        for n, p in self.named_parameters():
+            if p.grad is not None and p.grad.data_ptr() == st.gview(n).data_ptr():
+                return st.grad.clone()
+        return None
+
+    def _fused_backward(self, B, g):
+        eng = self._engine
+        plan, _ = eng._train_plan(B)
+        plan.run(first=eng.n_fwd_calls)
+        st = eng.store
+        if not (g.numel() == 1 and float(g) == 1.0):
+            st.grad.mul_(g)
+        if self._stash is not None:
+            st.grad.add_(self._stash)
+            self._stash = None
+        for n, p in self.named_parameters():
+            if p.requires_grad:
+                gv = st.gview(n)
+                if p.grad is None or p.grad.data_ptr() == gv.data_ptr():
+                    p.grad = gv
+                else:
+                    p.grad.add_(gv)
+
+    # ---- reference call contract ----
+    def forward(self, img, target=None, target_weight=None, img_metas=None, return_loss=True,
+                return_heatmap=False, **kwargs):
+        if return_loss:
+            return self.forward_train(img, target, target_weight, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, return_heatmap=return_heatmap, **kwargs)
+
+    def forward_train(self, img, target, target_weight, img_metas, **kwargs):
+        """top_down.py:143-161."""
+        if self._engine is not None and self.training and torch.is_grad_enabled():
+            _need_hip(img, 'TopDown.forward_train')
+            assert target.dim() == 4 and target_weight.dim() == 3
+            # the zero-size token makes autograd record the node although the plan owns the weights
+            loss = _FusedTrainFunction.apply(self, img.float(), target.float(), target_weight.float(),
+                                             *self.parameters())
+            losses = dict(heatmap_loss=loss)
+            if not (self.train_cfg or {}).get('skip_accuracy', False):
+                losses.update(self.keypoint_head.get_accuracy(self._heat, target, target_weight))
+            return losses
+        output = self.backbone(img)
+        if self.with_neck:
+            output = self.neck(output)
+        if self.with_keypoint:
+            output = self.keypoint_head(output)
+        losses = dict()
+        if self.with_keypoint:
+            losses.update(self.keypoint_head.get_loss(output, target, target_weight))
+            losses.update(self.keypoint_head.get_accuracy(output, target, target_weight))
+        return losses
+
+    def _infer_heatmap(self, img, flip_pairs=None):
+        """backbone + head.inference_model (-> host array); one fused plan when available."""
+        if self._engine is not None and not self.training:
+            _need_hip(img, 'TopDown.forward_test')
+            self._refresh()
+            heat = self._engine.infer(img.float(), copy_out=False).cpu().numpy()
+            if flip_pairs is not None:
+                heat = flip_back(heat, flip_pairs, target_type=self.keypoint_head.target_type)
+                if self.keypoint_head.test_cfg.get('shift_heatmap', False):
+                    heat[:, :, :, 1:] = heat[:, :, :, :-1]
+            return heat
+        features = self.backbone(img)
+        if self.with_neck:
+            features = self.neck(features)
+        return self.keypoint_head.inference_model(features, flip_pairs=flip_pairs)
+
+    @torch.no_grad()
+    def forward_test(self, img, img_metas, return_heatmap=False, **kwargs):
+        """top_down.py:163-200."""
+        assert img.size(0) == len(img_metas)
+        batch_size, _, img_height, img_width = img.shape
+        if batch_size > 1:
+            assert 'bbox_id' in img_metas[0]
+        result = {}
+        output_heatmap = self._infer_heatmap(img)
+        if self.test_cfg.get('flip_test', True):
+            output_flipped_heatmap = self._infer_heatmap(img.flip(3), img_metas[0]['flip_pairs'])
+            output_heatmap = (output_heatmap + output_flipped_heatmap) * 0.5
+        if self.with_keypoint:
+            result.update(self.keypoint_head.decode(img_metas, output_heatmap, img_size=[img_width, img_height]))
+            if not return_heatmap:
+                output_heatmap = None
+            result['output_heatmap'] = output_heatmap
+        return result
+
+    def forward_dummy(self, img):
+        """top_down.py:202-218."""
+        if self._engine is not None and not self.training and not torch.is_grad_enabled():
+            self._refresh()
+            return self._engine.infer(img.float())
+        output = self.backbone(img)
+        if self.with_neck:
+            output = self.neck(output)
+        if self.with_keypoint:
+            output = self.keypoint_head(output)
+        return output
+
+    @staticmethod
+    def _parse_losses(losses):
+        """detectors/base.py:38-76."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, float):
+                log_vars[name] = value
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors or float')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        for name, value in log_vars.items():
+            if not isinstance(value, float):
+                if dist.is_available() and dist.is_initialized():
+                    value = value.data.clone()
+                    dist.all_reduce(value.div_(dist.get_world_size()))
+                log_vars[name] = value.item()
+        return loss, log_vars
+
+    def train_step(self, data_batch, optimizer, **kwargs):
+        """detectors/base.py:78-113."""
+        losses = self.forward(**data_batch)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(next(iter(data_batch.values()))))
+
+    def val_step(self, data_batch, optimizer, **kwargs):
+        """detectors/base.py:115-126."""
+        return dict(results=self.forward(return_loss=False, **data_batch))
+
+    # ---- optimizer / data parallel (the reference builds these in mmpose/apis/train.py:116-200) ----
+    def build_optimizer(self, optimizer_cfg: dict, grad_clip: Optional[dict] = None):
+        """Fused layer-decay AdamW over the flat store from the reference's `optimizer=dict(type='AdamW',
+        ..., constructor='LayerDecayOptimizerConstructor', paramwise_cfg=dict(num_layers, layer_decay_rate))`
+        and `optimizer_config=dict(grad_clip=dict(max_norm, norm_type=2))` blocks."""
+        if self._engine is None:
+            raise RuntimeError('build_optimizer needs the fused model on a HIP device (model.cuda())')
+        cfg = dict(optimizer_cfg)
+        if cfg.pop('type', 'AdamW') != 'AdamW':
+            raise NotImplementedError('the HIP optimizer implements AdamW')
+        pw = cfg.get('paramwise_cfg') or {}
+        if grad_clip and grad_clip.get('norm_type', 2) != 2:
+            raise NotImplementedError('grad_clip norm_type must be 2')
+        frozen = [n for n, p in self.named_parameters() if not p.requires_grad]
+        self._engine.setup_optimizer(lr=cfg.get('lr', 1e-3), betas=tuple(cfg.get('betas', (0.9, 0.999))),
+                                     weight_decay=cfg.get('weight_decay', 1e-2),
+                                     layer_decay_rate=pw.get('layer_decay_rate', 1.0),
+                                     num_layers=pw.get('num_layers', self.backbone.depth),
+                                     max_grad_norm=(grad_clip or {}).get('max_norm', 0.0), frozen=frozen)
+        return _FlatOptimizer(self)
+
+    def enable_ddp(self, process_group=None, blocks_per_bucket=3):
+        """Batch-sharded data parallelism over RCCL: gradient buckets are all-reduced from inside the
+        backward plan (replaces MMDistributedDataParallel, mmpose/apis/train.py:116-133)."""
+        if self._engine is None:
+            raise RuntimeError('enable_ddp needs the fused model on a HIP device (model.cuda())')
+        return self._engine.enable_ddp(process_group, blocks_per_bucket)
+
+
+class _FlatOptimizer:
+    """step()/zero_grad() facade over the fused AdamW kernel (grad clip + layer decay inside)."""
+
+    def __init__(self, model: TopDown):
+        self.model = model
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def step(self, lr: Optional[float] = None):
+        # the kernel updates the master weights and their bf16 mirror in place (below torch's version
+        # counters), and optimizer_step re-derives the re-laid-out head weights / combined pos-embed
+        self.model._engine.optimizer_step(lr)

@@ -52,9 +52,11 @@ class Plan:
         self.use_tail_split = True
 
     # -- replay --
-    def run(self, stream=None):
+    def run(self, stream=None, first=0, last=None):
+        """Replay calls [first, last) on `stream` (default: torch's current HIP stream)."""
         s = c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
-        for name, fn, args in self.calls:
+        calls = self.calls if first == 0 and last is None else self.calls[first:last]
+        for name, fn, args in calls:
             rc = fn(*args, s)
             if rc != 0:
                 raise KernelError(f'{name} failed with status {rc}')

@@ -146,11 +146,11 @@ class PoseEngine:
         return io['loss'], io['heat']
 
     def setup_optimizer(self, lr=5e-4, betas=(0.9, 0.999), weight_decay=0.1, layer_decay_rate=0.75,
-                        num_layers=None, max_grad_norm=1.0):
+                        num_layers=None, max_grad_norm=1.0, frozen=()):
         from .optim import FlatAdamW, layer_decay_param_groups
         groups = layer_decay_param_groups(self.named_shapes(), num_layers or self.vit.depth, layer_decay_rate,
                                           lr, weight_decay)
-        self.optimizer = FlatAdamW(self.store, groups, lr, betas, 1e-8, max_grad_norm)
+        self.optimizer = FlatAdamW(self.store, groups, lr, betas, 1e-8, max_grad_norm, frozen=frozen)
         return self.optimizer
 
     def optimizer_step(self, lr=None, grad_scale=None):
