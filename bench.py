@@ -1,16 +1,21 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec of the ViTPose-B (classic decoder) training step at
-256x192 on N MI355X GPUs, one process per GPU.
+256x192 on N MI355X GPUs, one process per GPU, through the reference's own model API:
+the model is built from a reference-shaped `model=dict(type='TopDown', ...)` config by the
+registry (`build_posenet`), moved to the GPU and driven as the reference's runner drives it
+(forward_train -> loss.backward() -> optimizer step).
 
 A step = forward + backward (DropPath on, BatchNorm batch statistics) + gradient all-reduce
 (N > 1) + global-norm clip + layer-decay AdamW, on one synthetic batch of 64 images per GPU
-(weak scaling; global batch 512 at 8 GPUs = BASELINE.json config 3; at N=1 this is the
-fwd+bwd metric workload on one GPU).  Inputs are resident in HBM before the timed region.
+(weak scaling; global batch 512 at 8 GPUs; at N=1 this is the fwd+bwd metric workload on one
+GPU).  Inputs are resident in HBM before the timed region.  The PCK accuracy that the reference
+logs every 50 iterations is not part of the step (`train_cfg.skip_accuracy`).
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --mode infer --model B --batch 64      (BASELINE config 2: one eval forward)
 
-Rank 0 prints ONE JSON line (schema in the repo's DESIGN.md).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -36,61 +41,71 @@ EPI_NAMES = {0: 'VP_EPI_BF16', 1: 'VP_EPI_GELU', 2: 'VP_EPI_RESID_F32', 3: 'VP_E
              5: 'VP_EPI_F32', 6: 'VP_EPI_SCALE_RELU', 7: 'VP_EPI_DRELU'}
 
 
-def vit_cfg(m):
-    return dict(img_size=(256, 192), patch_size=16, in_chans=3, embed_dim=m['embed_dim'], depth=m['depth'],
-                num_heads=m['num_heads'], mlp_ratio=4, qkv_bias=True, ratio=1, last_norm=True,
-                drop_path_rate=m['drop_path_rate'])
+def model_cfg(m):
+    """The `model` block of configs/body/2d_kpt_sview_rgb_img/topdown_heatmap/coco/ViTPose_base_coco_256x192.py
+    (and its small / large siblings): same keys, same values."""
+    return dict(
+        type='TopDown', pretrained=None,
+        backbone=dict(type='ViT', img_size=(256, 192), patch_size=16, embed_dim=m['embed_dim'], depth=m['depth'],
+                      num_heads=m['num_heads'], ratio=1, use_checkpoint=False, mlp_ratio=4, qkv_bias=True,
+                      drop_path_rate=m['drop_path_rate']),
+        keypoint_head=dict(type='TopdownHeatmapSimpleHead', in_channels=m['embed_dim'], num_deconv_layers=2,
+                           num_deconv_filters=(256, 256), num_deconv_kernels=(4, 4),
+                           extra=dict(final_conv_kernel=1), out_channels=17,
+                           loss_keypoint=dict(type='JointsMSELoss', use_target_weight=True)),
+        train_cfg=dict(skip_accuracy=True),
+        test_cfg=dict(flip_test=False, post_process='default', shift_heatmap=False, target_type='GaussianHeatmap',
+                      modulate_kernel=11, use_udp=False))
 
 
-def head_cfg(E):
-    return dict(in_channels=E, out_channels=17, num_deconv_layers=2, num_deconv_filters=(256, 256),
-                num_deconv_kernels=(4, 4), extra=dict(final_conv_kernel=1), upsample=0)
-
-
-def random_init_state(eng, seed=0):
-    """Random-init weights of the reference's recipe (trunc_normal .02 Linear / pos_embed, LN (1,0),
-    head normal .001): values do not affect speed, shapes are ViTPose-B's."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-    for n, s in eng.named_shapes():
-        if 'norm' in n and n.endswith('.weight') or (n.startswith('keypoint_head.deconv') and len(s) == 1 and n.endswith('weight')):
-            sd[n] = torch.ones(s)
-        elif n.endswith('.bias') or len(s) == 1:
-            sd[n] = torch.zeros(s)
-        elif n.startswith('keypoint_head.'):
-            sd[n] = torch.randn(s, generator=g) * 0.001
-        else:
-            sd[n] = torch.nn.init.trunc_normal_(torch.empty(s), std=0.02, generator=g)
-    return sd
-
-
-def cpu_baseline(model_key, batch, iters=3):
-    """The CPU oracle (torch fp32 restatement of the reference ops) timed on this box's host cores:
-    forward + backward of the same model on a bounded sample."""
+def cpu_baseline(model_key, batch, mode, iters=3):
+    """The CPU oracle (torch fp32 restatement of the reference ops) timed on this box's host cores
+    on a bounded sample of the same workload."""
     from oracle import vitpose_oracle as O
     m = MODELS[model_key]
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    vcfg, hc = vit_cfg(m), head_cfg(m['embed_dim'])
-    bb = {k: v.requires_grad_() for k, v in O.synth_vit_weights(vcfg, seed=0).items()}
+    vcfg = O.vit_cfg(model_key) if model_key in O.VIT_CFGS else None
+    hc = O.classic_head_cfg(m['embed_dim'])
+    bb = O.synth_vit_weights(vcfg, seed=0)
     hd = O.synth_head_weights(hc, seed=1)
-    for k, v in hd.items():
-        if 'running' not in k:
-            v.requires_grad_()
     img, target, tw = O.synth_batch(batch, seed=2)
+    if mode == 'train':
+        for v in bb.values():
+            v.requires_grad_()
+        for k, v in hd.items():
+            if 'running' not in k:
+                v.requires_grad_()
 
-    def step():
-        heat = O.head_forward(hd, O.vit_forward(bb, img, vcfg), hc, training=True)
-        O.joints_mse_loss(heat, target, tw).backward()
+        def step():
+            heat = O.head_forward(hd, O.vit_forward(bb, img, vcfg), hc, training=True)
+            O.joints_mse_loss(heat, target, tw).backward()
+        what = 'forward+backward (no optimizer)'
+    else:
+        def step():
+            with torch.no_grad():
+                O.head_forward(hd, O.vit_forward(bb, img, vcfg), hc, training=False)
+        what = 'eval forward'
     step()
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
     dt = time.perf_counter() - t0
     return dict(value=round(batch * iters / dt, 3), unit='images/sec', cores=cores, kind='port',
-                sample=f'oracle/vitpose_oracle.py fp32 forward+backward (no optimizer), ViTPose-{model_key} classic, '
-                       f'batch {batch}, {iters} timed iterations after 1 warm-up, torch {torch.__version__} CPU, '
-                       f'{cores} threads')
+                sample=f'oracle/vitpose_oracle.py fp32 {what}, ViTPose-{model_key} classic, batch {batch}, '
+                       f'{iters} timed iterations after 1 warm-up, torch {torch.__version__} CPU, {cores} threads')
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by tools/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(kernel_key, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -99,6 +114,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--model', default='B', choices=list(MODELS))
+    ap.add_argument('--mode', default='train', choices=['train', 'infer'])
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -116,43 +132,72 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
 
-    from vitpose_amd.pose_engine import PoseEngine
+    import vitpose_amd.models  # noqa: F401  (registers ViT / TopdownHeatmapSimpleHead / JointsMSELoss / TopDown)
+    from vitpose_amd.builder import build_posenet
     m = MODELS[args.model]
-    eng = PoseEngine(vit_cfg(m), head_cfg(m['embed_dim']), dev)
-    eng.load_state_dict(random_init_state(eng, seed=0))   # identical replicas on every rank
-    eng.setup_optimizer(lr=5e-4, weight_decay=0.1, layer_decay_rate=m['layer_decay'], max_grad_norm=1.0)
-    if world > 1:
-        eng.enable_ddp()
+    torch.manual_seed(0)                                    # identical random-init replicas on every rank
+    model = build_posenet(model_cfg(m)).to(dev)             # reference init: trunc_normal .02 / head normal .001
+    eng = model._engine
+    assert eng is not None, 'the fused HIP plan must be active'
     B = args.batch
     g = torch.Generator().manual_seed(1000 + rank)          # each rank its own shard of the global batch
     img = torch.randn(B, 3, 256, 192, generator=g).to(dev)
     target = torch.rand(B, 17, 64, 48, generator=g).to(dev)
     tw = torch.ones(B, 17, 1).to(dev)
 
-    def step(timers=None):
-        eng.forward_backward(img, target, tw, drop_path=True, timers=timers)
-        eng.optimizer_step()
+    if args.mode == 'train':
+        model.train()
+        opt = model.build_optimizer(
+            dict(type='AdamW', lr=5e-4, betas=(0.9, 0.999), weight_decay=0.1,
+                 constructor='LayerDecayOptimizerConstructor',
+                 paramwise_cfg=dict(num_layers=m['depth'], layer_decay_rate=m['layer_decay'])),
+            grad_clip=dict(max_norm=1., norm_type=2))
+        if world > 1:
+            model.enable_ddp()
 
-    for _ in range(args.warmup):
-        step()
+        def step():
+            losses = model.forward_train(img, target, tw, None)
+            losses['heatmap_loss'].backward()
+            opt.step()
+            opt.zero_grad()
+            return losses['heatmap_loss']
+        plan_of = lambda: eng.plans[('train', B)][0]  # noqa: E731
+        gflop = m['train_gflop']
+        what = (f'ViTPose-{args.model} 256x192 classic-decoder training step (fwd+bwd+grad-clip+AdamW, DropPath on, '
+                f'BN batch stats) via TopDown.forward_train, {B} img/GPU, global batch {world * B}, random-init weights')
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model.forward_dummy(img)
+        plan_of = lambda: eng.plans[('infer', B)][0]  # noqa: E731
+        gflop = m['fwd_gflop']
+        what = (f'ViTPose-{args.model} 256x192 classic-decoder inference (one eval forward, flip_test off as in '
+                f'tools/analysis/speed_test.py) via TopDown.forward_dummy, batch {B}/GPU, random-init weights')
+
+    last = None
+    for _ in range(max(1, args.warmup)):
+        last = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     timers = []
+    plan_of().timers = timers      # HIP-event pair around every GEMM launch, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(timers)
+        last = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    plan_of().timers = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss = float(eng.plans[('train', B)][1]['loss'].item())
 
     # per-kernel (template instantiation) GEMM timing from the HIP events of the timed region
     groups = {}
@@ -168,24 +213,19 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
+        kname = f'gemm_kernel<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi}>'
         out = {
             'metric': 'images/sec (256x192) ViTPose-B fwd+bwd at 1/2/4/8 GPUs; % bf16 MFMA roofline',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'ViTPose-{args.model} 256x192 classic-decoder training step '
-                                   f'(fwd+bwd+grad-clip+AdamW, DropPath on, BN batch stats), {B} img/GPU, '
-                                   f'global batch {world * B}, random-init weights',
-                       'parallelism': f'dp{world}', 'global_batch': world * B},
-            'step_tflops_per_gpu': round(value * m['train_gflop'] / world / 1e3, 2),
-            'frac_of_bf16_mfma_peak': round(value * m['train_gflop'] / world / 1e3 / PEAK_BF16_TFLOPS, 4),
-            'loss': loss,
+            'config': {'workload': what, 'parallelism': f'dp{world}', 'global_batch': world * B},
+            'step_tflops_per_gpu': round(value * gflop / world / 1e3, 2),
+            'frac_of_bf16_mfma_peak': round(value * gflop / world / 1e3 / PEAK_BF16_TFLOPS, 4),
             'roofline': {
-                'bound': 'mfma',
-                'kernel': f'gemm_kernel<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi}>'
-                          f' ({EPI_NAMES[epi]})',
+                'bound': 'mfma', 'kernel': f'{kname} ({EPI_NAMES[epi]})',
                 'achieved': round(dflop / dsec / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(dflop / dsec / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                'frac': round(dflop / dsec / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic(kname),
                 'launches': dn, 'avg_launch_us': round(dsec / dn * 1e6, 2),
                 'algorithmic_gflop_per_launch': round(dflop / dn / 1e9, 3),
                 'share_of_step_time': round(dsec / dt, 3),
@@ -195,8 +235,10 @@ def main():
                              for (xk_, yk_, e_), d in sorted(groups.items())},
             'all_gemms': {'tflops': round(tot_f / tot_t / 1e12, 2), 'share_of_step_time': round(tot_t / dt, 3)},
         }
+        if args.mode == 'train':
+            out['loss'] = float(last.item())
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_batch)
+            out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_batch, args.mode)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

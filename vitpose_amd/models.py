@@ -879,6 +879,7 @@ class TopDown(nn.Module):
         bb._store = hd._store = st
         bb._prefix, hd._prefix = 'backbone.', 'keypoint_head.'
         bb._seen_version = hd._seen_version = None
+        self._grad_views = [(p, st.gview(n)) for n, p in self.named_parameters()]
         self._engine = eng
         self._seen_version = None
 
@@ -911,10 +912,9 @@ class TopDown(nn.Module):
         return io['loss'].reshape(()).clone()
 
     def _stash_live(self):
-        st = self._engine.store
-        for n, p in self.named_parameters():
-            if p.grad is not None and p.grad.data_ptr() == st.gview(n).data_ptr():
-                return st.grad.clone()
+        for p, gv in self._grad_views:
+            if p.grad is not None and p.grad.data_ptr() == gv.data_ptr():
+                return self._engine.store.grad.clone()
         return None
 
     def _fused_backward(self, B, g):
@@ -927,9 +927,8 @@ class TopDown(nn.Module):
         if self._stash is not None:
             st.grad.add_(self._stash)
             self._stash = None
-        for n, p in self.named_parameters():
+        for p, gv in self._grad_views:
             if p.requires_grad:
-                gv = st.gview(n)
                 if p.grad is None or p.grad.data_ptr() == gv.data_ptr():
                     p.grad = gv
                 else:

@@ -50,10 +50,13 @@ class Plan:
         self.keep = []      # tensors / ctypes objects that must outlive the plan
         self.tags = {}      # call index -> (x_kmajor, y_kmajor, epilogue, M, N, K) of GEMM launches
         self.use_tail_split = True
+        self.timers = None  # a list: run() then brackets every GEMM launch with HIP events (see run_timed)
 
     # -- replay --
     def run(self, stream=None, first=0, last=None):
         """Replay calls [first, last) on `stream` (default: torch's current HIP stream)."""
+        if self.timers is not None and stream is None:
+            return self.run_timed(self.timers, first, last)
         s = c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
         calls = self.calls if first == 0 and last is None else self.calls[first:last]
         for name, fn, args in calls:
@@ -61,13 +64,15 @@ class Plan:
             if rc != 0:
                 raise KernelError(f'{name} failed with status {rc}')
 
-    def run_timed(self, timers):
+    def run_timed(self, timers, first=0, last=None):
         """Replay with a HIP event pair around every GEMM launch (events are recorded on the
         stream the kernels are launched on).  `timers` is a list that receives
         (gemm_tag, start_event, end_event); read elapsed times after a synchronize."""
         st = torch.cuda.current_stream()
         s = c_void_p(st.cuda_stream)
-        for i, (name, fn, args) in enumerate(self.calls):
+        last = len(self.calls) if last is None else last
+        for i in range(first, last):
+            name, fn, args = self.calls[i]
             tag = self.tags.get(i)
             if tag is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
