@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--embed', type=int, default=768)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', default='')
+    ap.add_argument('--tile-mode', type=int, default=0, help='0 heuristic, 1 = 128x128 tiles, 2 = 256x256 tiles')
+    ap.add_argument('--wsplit', type=int, default=0, help='override the wgrad K split')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     M, E = args.tokens, args.embed
@@ -32,18 +34,19 @@ def main():
         x, w = rb(M, K), rb(N, K)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         cases.append((f'fwd_{name}   M{M} N{N} K{K}', 2.0 * M * N * K,
-                      lambda p, x=x, w=w, out=out, N=N, K=K: p.gemm(x, w, out, M, N, K, ldx=K, ldy=K, ldo=N)))
+                      lambda p, x=x, w=w, out=out, N=N, K=K: p.gemm(x, w, out, M, N, K, ldx=K, ldy=K, ldo=N,
+                                                                       tile_mode=args.tile_mode)))
         dy = rb(M, N)
         dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
         cases.append((f'dgrad_{name} M{M} N{K} K{N}', 2.0 * M * N * K,
                       lambda p, dy=dy, w=w, dx=dx, N=N, K=K: p.gemm(dy, w, dx, M, K, N, ldx=N, ldy=K, ldo=K,
-                                                                    y_kmajor=True)))
+                                                                    y_kmajor=True, tile_mode=args.tile_mode)))
         dw = torch.empty(N, K, device=dev)
         slab = torch.empty(_slab_elems(N * K, M), device=dev)
-        sk = _split_k(N, K, M)
+        sk = args.wsplit or _split_k(N, K, M)
         cases.append((f'wgrad_{name} M{N} N{K} K{M} split{sk}', 2.0 * M * N * K,
                       lambda p, dy=dy, x=x, dw=dw, slab=slab, N=N, K=K, sk=sk: p.wgrad(
-                          dy, x, dw, N, K, M, ldx=N, ldy=K, split_k=sk, slab=slab)))
+                          dy, x, dw, N, K, M, ldx=N, ldy=K, split_k=sk, slab=slab, tile_mode=args.tile_mode)))
     for name, flops, build in cases:
         if args.only and args.only not in name:
             continue

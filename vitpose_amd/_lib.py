@@ -31,7 +31,7 @@ class GemmArgs(Structure):
         ('pos', c_void_p), ('pos_rows', c_int),
         ('split_k', c_int), ('split_stride', c_long),
         ('out_row_div', c_int), ('out_row_hi', c_int), ('out_row_lo', c_int), ('out_row_off', c_int),
-        ('tail_ws', c_void_p), ('tail_ws_bytes', c_size_t), ('tail_force', c_int),
+        ('tail_ws', c_void_p), ('tail_ws_bytes', c_size_t), ('tail_force', c_int), ('tile_mode', c_int),
     ]
 
 

@@ -107,22 +107,131 @@ struct Epi {
 // (DropPath scale, residual / position row pointer, remapped output row) operands are fetched
 // before the 4x4 tile loop, and loads inside the loop use clamped in-bounds addresses, so the
 // loop body is branch-free apart from the predicated store and its loads can be batched.
-template <int EPI>
-__device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[4][4], int i0, int j0, int wm, int wn,
-                                             int lane, int M, int N) {
+#ifdef VP_ABLATE_NOSTORE
+#define VP_ST_OK(c) ((c) && e.ldo < 0)   /* ablation build: keeps the values live, never stores */
+#else
+#define VP_ST_OK(c) (c)
+#endif
+
+template <int EPI, int FM, int FN>
+__device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
+                                             int M, int N) {
     const int g = lane >> 4, li = lane & 15;
-    int col[4];
-    bool cok[4];
-    f32x4 bias[4], cs[4];
+    int col[FN];
+    bool cok[FN];
+    f32x4 bias[FN], cs[FN];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int c = j0 + wn * 64 + b * 16 + g * 4;
+    for (int b = 0; b < FN; ++b) {
+        const int c = col0 + b * 16 + g * 4;
         cok[b] = c + 3 < N;
         col[b] = cok[b] ? c : N - 4;
         bias[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         cs[b] = f32x4{1.f, 1.f, 1.f, 1.f};
     }
     if constexpr (EPI != VP_EPI_SPLITK_F32 && EPI != VP_EPI_DGELU && EPI != VP_EPI_DRELU) {
+        if (e.bias) {
+#pragma unroll
+            for (int b = 0; b < FN; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
+        }
+    }
+    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU) {
+        if (e.colscale) {
+#pragma unroll
+            for (int b = 0; b < FN; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+        const int row_raw = row0 + a * 16 + li;
+        const bool rok = row_raw < M;
+        const int row = rok ? row_raw : M - 1;
+        const size_t orow = e.row_div > 0
+                                ? (size_t)(row / e.row_div) * e.row_hi + (row % e.row_div) * e.row_lo + e.row_off
+                                : (size_t)row;
+        if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
+            bf16* o = (bf16*)e.out + orow * e.ldo;
+            bf16* o2 = EPI == VP_EPI_GELU && e.out2 ? (bf16*)e.out2 + orow * e.ldo : nullptr;
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                f32x4 v = acc[a][b] * cs[b] + bias[b];
+                const bool ok = rok && cok[b];
+                if constexpr (EPI == VP_EPI_GELU) {
+                    if (o2 && VP_ST_OK(ok)) *reinterpret_cast<bf16x4*>(o2 + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                if constexpr (EPI == VP_EPI_SCALE_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (VP_ST_OK(ok)) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        } else if constexpr (EPI == VP_EPI_RESID_F32) {
+            // out = addend + rowscale[row / rows_per_scale] * (acc + bias), addend = resid row or pos row
+            const float rs = e.rowscale ? e.rowscale[row / e.rows_per_scale] : 1.f;
+            const float* add = e.resid ? e.resid + (size_t)row * e.ldo
+                                       : (e.pos ? e.pos + (size_t)(row % e.pos_rows) * e.ldo : nullptr);
+            float* o = (float*)e.out + orow * e.ldo;
+            f32x4 ad[FN];
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+                ad[b] = add ? *reinterpret_cast<const f32x4*>(add + col[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                const f32x4 v = ad[b] + (acc[a][b] + bias[b]) * rs;
+                if (VP_ST_OK(rok && cok[b])) *reinterpret_cast<f32x4*>(o + col[b]) = v;
+            }
+        } else if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
+            const bf16* ax = (const bf16*)e.aux + (size_t)row * e.ldaux;
+            bf16* o = (bf16*)e.out + orow * e.ldo;
+            bf16x4 u[FN];
+#pragma unroll
+            for (int b = 0; b < FN; ++b) u[b] = *reinterpret_cast<const bf16x4*>(ax + col[b]);
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                f32x4 v = acc[a][b];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (EPI == VP_EPI_DGELU) v[r] *= gelu_erf_grad((float)u[b][r]);
+                    else v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
+                }
+                if (VP_ST_OK(rok && cok[b])) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        } else {  // VP_EPI_F32, VP_EPI_SPLITK_F32 (slice blockIdx.y of the partial-sum slab)
+            float* o = (float*)e.out + orow * e.ldo;
+            if constexpr (EPI == VP_EPI_SPLITK_F32) o += (size_t)blockIdx.y * e.split_stride;
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                const f32x4 v = acc[a][b] + bias[b];
+                if (VP_ST_OK(rok && cok[b])) *reinterpret_cast<f32x4*>(o + col[b]) = v;
+            }
+        }
+    }
+}
+
+// bf16 outputs: a lane of the accumulator layout owns 4 consecutive columns (8 bytes), and 8-byte
+// row-scattered stores leave the chip at ~2.5 TB/s (store-issue bound).  The wave's 64 x 64 block is
+// therefore transposed through a wave-private LDS region (row pitch 144 B: conflict-free 8-byte
+// writes, 16-byte aligned reads) and written as 16 bytes per lane, 128 contiguous bytes per row.
+constexpr int STG_PITCH = 144;
+constexpr int STG_BYTES = 64 * STG_PITCH;
+
+template <int EPI, int FM>
+__device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[FM][4], int row0, int col0, int lane,
+                                                    int M, int N, char* stg) {
+    static_assert(EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU || EPI == VP_EPI_DGELU ||
+                  EPI == VP_EPI_DRELU, "bf16 outputs only");
+    const int g = lane >> 4, li = lane & 15;
+    int col[4];
+    f32x4 bias[4], cs[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int c = col0 + b * 16 + g * 4;
+        col[b] = c + 3 < N ? c : N - 4;
+        bias[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs[b] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
         if (e.bias) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
@@ -134,73 +243,69 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[4][4], i
             for (int b = 0; b < 4; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
         }
     }
+    constexpr int NPASS = EPI == VP_EPI_GELU ? 2 : 1;   // GELU: pass 0 = pre-activation copy (out2), pass 1 = out
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int row_raw = i0 + wm * 64 + a * 16 + li;
-        const bool rok = row_raw < M;
-        const int row = rok ? row_raw : M - 1;
-        const size_t orow = e.row_div > 0
-                                ? (size_t)(row / e.row_div) * e.row_hi + (row % e.row_div) * e.row_lo + e.row_off
-                                : (size_t)row;
-        if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
-            bf16* o = (bf16*)e.out + orow * e.ldo;
-            bf16* o2 = EPI == VP_EPI_GELU && e.out2 ? (bf16*)e.out2 + orow * e.ldo : nullptr;
+    for (int half = 0; half < FM / 4; ++half) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                f32x4 v = acc[a][b] * cs[b] + bias[b];
-                const bool ok = rok && cok[b];
-                if constexpr (EPI == VP_EPI_GELU) {
-                    if (o2 && ok) *reinterpret_cast<bf16x4*>(o2 + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (EPI == VP_EPI_GELU && pass == 0 && !e.out2) continue;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            for (int a = 0; a < 4; ++a) {
+                const int A = half * 4 + a;
+                bf16x4 u[4];
+                if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
+                    const int row_raw = row0 + A * 16 + li;
+                    const int row = row_raw < M ? row_raw : M - 1;
+                    const bf16* ax = (const bf16*)e.aux + (size_t)row * e.ldaux;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) u[b] = *reinterpret_cast<const bf16x4*>(ax + col[b]);
                 }
-                if constexpr (EPI == VP_EPI_SCALE_RELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int b = 0; b < 4; ++b) {
+                    f32x4 v;
+                    if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
+                        v = acc[A][b];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (EPI == VP_EPI_DGELU) v[r] *= gelu_erf_grad((float)u[b][r]);
+                            else v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
+                        }
+                    } else {
+                        v = acc[A][b] * cs[b] + bias[b];
+                        if (EPI == VP_EPI_GELU && pass == 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        }
+                        if constexpr (EPI == VP_EPI_SCALE_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                    }
+                    *reinterpret_cast<bf16x4*>(stg + (a * 16 + li) * STG_PITCH + (b * 16 + g * 4) * 2) =
+                        pack4(v[0], v[1], v[2], v[3]);
                 }
-                if (ok) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
             }
-        } else if constexpr (EPI == VP_EPI_RESID_F32) {
-            // out = addend + rowscale[row / rows_per_scale] * (acc + bias), addend = resid row or pos row
-            const float rs = e.rowscale ? e.rowscale[row / e.rows_per_scale] : 1.f;
-            const float* add = e.resid ? e.resid + (size_t)row * e.ldo
-                                       : (e.pos ? e.pos + (size_t)(row % e.pos_rows) * e.ldo : nullptr);
-            float* o = (float*)e.out + orow * e.ldo;
-            f32x4 ad[4];
+            bf16* dst = (EPI == VP_EPI_GELU && pass == 0) ? (bf16*)e.out2 : (bf16*)e.out;
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                ad[b] = add ? *reinterpret_cast<const f32x4*>(add + col[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const f32x4 v = ad[b] + (acc[a][b] + bias[b]) * rs;
-                if (rok && cok[b]) *reinterpret_cast<f32x4*>(o + col[b]) = v;
-            }
-        } else if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
-            const bf16* ax = (const bf16*)e.aux + (size_t)row * e.ldaux;
-            bf16* o = (bf16*)e.out + orow * e.ldo;
-            bf16x4 u[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) u[b] = *reinterpret_cast<const bf16x4*>(ax + col[b]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                f32x4 v = acc[a][b];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (EPI == VP_EPI_DGELU) v[r] *= gelu_erf_grad((float)u[b][r]);
-                    else v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
+            for (int i = 0; i < 8; ++i) {
+                const int id = i * 64 + lane, r = id >> 3, c = id & 7;
+                const int grow = row0 + half * 64 + r, gcol = col0 + c * 8;
+                const uint4 val = *reinterpret_cast<const uint4*>(stg + r * STG_PITCH + c * 16);
+                if (VP_ST_OK(grow < M && gcol + 7 < N)) {
+                    const size_t orow = e.row_div > 0 ? (size_t)(grow / e.row_div) * e.row_hi +
+                                                            (grow % e.row_div) * e.row_lo + e.row_off
+                                                      : (size_t)grow;
+                    *reinterpret_cast<uint4*>(dst + orow * e.ldo + gcol) = val;
                 }
-                if (rok && cok[b]) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
-            }
-        } else {  // VP_EPI_F32, VP_EPI_SPLITK_F32 (slice blockIdx.y of the partial-sum slab)
-            float* o = (float*)e.out + orow * e.ldo;
-            if constexpr (EPI == VP_EPI_SPLITK_F32) o += (size_t)blockIdx.y * e.split_stride;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const f32x4 v = acc[a][b] + bias[b];
-                if (rok && cok[b]) *reinterpret_cast<f32x4*>(o + col[b]) = v;
             }
         }
     }
+}
+
+template <int EPI>
+constexpr bool epi_is_bf16() {
+    return EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU || EPI == VP_EPI_DGELU ||
+           EPI == VP_EPI_DRELU;
 }
 
 template <bool XKMAJ, bool YKMAJ, int EPI>
@@ -289,7 +394,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
             for (int b = 0; b < 4; ++b) w[(a * 4 + b) * NTHREADS] = acc[a][b];
         return;
     }
-    run_epilogue<EPI>(e, acc, i0, j0, wm, wn, lane, M, N);
+    if constexpr (epi_is_bf16<EPI>()) {
+        if (((N | e.ldo) & 7) == 0) {   // (the loop's last barrier: every wave is done with the operand tiles)
+            run_epilogue_staged<EPI, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N,
+                                        &lds[0][0][0] + wave * STG_BYTES);
+            return;
+        }
+    }
+    run_epilogue<EPI, 4, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N);
 }
 
 // One workgroup per tail tile: sum the K-slice partials (same thread <-> fragment mapping as
@@ -324,7 +436,190 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tail_fixup(int M, int N, int ti
             acc[a][b] = s;
         }
     }
-    run_epilogue<EPI>(e, acc, i0, j0, wm, wn, lane, M, N);
+    run_epilogue<EPI, 4, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N);
+}
+
+// =====================================================================================
+// 256 x 256 x 64 tile, 512 threads, one workgroup per CU ("ping-pong" schedule)
+// =====================================================================================
+// Waves 0-3 (group 0) own C rows [0,128) of the tile, waves 4-7 (group 1) rows [128,256); wave
+// (g, wc) owns the 128 x 64 block at columns 64*wc: 8 x 4 MFMA fragments, computed per K tile
+// as four 64 x 32 quadrants of 16 MFMAs.  Each quadrant is a phase  [R: LDS reads + LDS-DMA
+// issue | barrier | C: 16 MFMAs | barrier];  group 1 runs ONE barrier behind group 0, so in
+// every barrier interval one wave of each SIMD streams MFMAs while its partner reads LDS and
+// issues loads -- the matrix pipe never waits for LDS, and no fragment is double-buffered.
+//
+// LDS: 2 stages x 4 half tiles (X rows 0-127, X rows 128-255, Y cols 0-127, Y cols 128-255;
+// 16 KiB each, images as in the 128 x 128 kernel).  Every half tile is filled by all 512
+// threads (2 LDS-DMA instructions each).  Schedule for K tile u (R(u,q) = read part of phase q):
+//   R(u,0) reads X rows-quadrant 0 + Y column-quadrant 0, issues Y1(u+1)
+//   R(u,1) reads Y column-quadrant 1,                      issues X0(u+1)
+//   R(u,2) reads X rows-quadrant 1,                        issues X1(u+1)
+//   R(u,3) reads nothing,                                  issues Y0(u+2)   (Y halves are free after R(u,1))
+// so a slot is overwritten at least two barrier intervals after its last read and every load
+// has at least three intervals to land.  Two counted waits per K tile make the data visible:
+// vmcnt(4) at the end of R(u,3) (all but {X1(u+1), Y0(u+2)} landed: group 0 reads X0/Y(u+1) in
+// the next interval) and vmcnt(2) at the end of C(u,3) (X1(u+1) landed: group 1 reads it two
+// intervals later); each is followed by the barrier that every reader passes first.  Loads
+// beyond the K range are still issued (clamped source, dead slot) so the counts stay exact.
+constexpr int T2 = 256, T2_THREADS = 512, HALF_BYTES = 128 * BK * 2;
+
+template <bool KMAJ>
+__device__ __forceinline__ void stage_half(const Operand& op, int r0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int base = (i * 8 + wave) * 64;
+        const int L = base + lane;
+        const bf16* src;
+        if constexpr (!KMAJ) {
+            const int r = L >> 3, c = (L & 7) ^ (r & 7);
+            int row = r0 + r;
+            row = row < op.rows ? row : op.rows - 1;
+            src = op.p + (size_t)row * op.ld + k0 + c * 8;
+        } else {
+            const int kr = L >> 4, s16 = L & 15;
+            const int unit = (s16 >> 1) ^ kmaj_key(kr);
+            int col = r0 + (unit * 2 + (s16 & 1)) * 8;
+            col = col <= op.rows - 8 ? col : op.rows - 8;
+            src = op.p + (size_t)(k0 + kr) * op.ld + col;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
+    }
+}
+
+#define VP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <bool XKMAJ, bool YKMAJ, int EPI>
+__global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Operand Y, int M, int N, int K,
+                                                                int tiles_n, int ntiles, int ksplit_tiles, Epi e) {
+    __shared__ __attribute__((aligned(16))) char lds[2][4][HALF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tiles_m = ntiles / tiles_n;
+    const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
+    const int gm = min(tiles_m - gid * 8, 8);
+    const int i0 = (gid * 8 + tin % gm) * T2, j0 = (tin / gm) * T2;
+    const int nk_all = K / BK;
+    const int kt0 = blockIdx.y * ksplit_tiles;
+    const int kt1 = min(nk_all, kt0 + ksplit_tiles);
+    const int nk = kt1 - kt0;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        // slot 0/1 = X halves, 2/3 = Y halves; K tile u (relative) lives in stage u & 1
+        auto stage = [&](int slot, int u) {
+            const int k0 = (kt0 + (u < nk ? u : nk - 1)) * BK;
+            char* dst = lds[u & 1][slot];
+            if (slot < 2) stage_half<XKMAJ>(X, i0 + slot * 128, k0, dst, wave, lane);
+            else stage_half<YKMAJ>(Y, j0 + (slot - 2) * 128, k0, dst, wave, lane);
+        };
+        stage(0, 0);
+        stage(1, 0);
+        stage(2, 0);
+        stage(3, 0);
+        stage(2, 1);
+        VP_WAIT_VM(2);
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
+
+        const int ycol = (wc & 1) * 64;
+#pragma unroll 1
+        for (int u = 0; u < nk; ++u) {
+            const char* lx = lds[u & 1][grp];
+            const char* ly = lds[u & 1][2 + (wc >> 1)];
+            bf16x8 xf[4][2], y0[2][2], y1[2][2];
+            // ---- phase 0
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) y0[b][s] = read_frag<YKMAJ>(ly, ycol + b * 16, s, lane);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) xf[a][s] = read_frag<XKMAJ>(lx, a * 16, s, lane);
+            }
+            stage(3, u + 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) y1[b][s] = read_frag<YKMAJ>(ly, ycol + 32 + b * 16, s, lane);
+            stage(0, u + 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][s], xf[a][s], acc[a][2 + b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) xf[a][s] = read_frag<XKMAJ>(lx, 64 + a * 16, s, lane);
+            stage(1, u + 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[4 + a][2 + b] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][s], xf[a][s], acc[4 + a][2 + b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3
+            stage(2, u + 2);
+            VP_WAIT_VM(4);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][s], xf[a][s], acc[4 + a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            VP_WAIT_VM(2);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();   // match group 1's extra barrier
+        VP_WAIT_VM(0);                                 // no LDS-DMA may outlive the workgroup
+    }
+    if constexpr (epi_is_bf16<EPI>()) {
+        if (((N | e.ldo) & 7) == 0) {
+            __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free for staging
+            run_epilogue_staged<EPI, 8>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N,
+                                        &lds[0][0][0] + wave * STG_BYTES);
+            return;
+        }
+    }
+    run_epilogue<EPI, 8, 4>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N);
 }
 
 inline int num_cus() {
@@ -338,6 +633,13 @@ inline int num_cus() {
             n = 256;
     }
     return n;
+}
+
+// Heuristic: the big tile pays when its workgroups keep most CUs busy in whole rounds.
+inline bool use_big_tiles(int M, int N, int K, int units, int cus) {
+    if (M < 2 * T2 || N < T2 || K < 4 * BK) return false;
+    const int rounds = (units + cus - 1) / cus;
+    return (double)units / (double)(rounds * cus) >= 0.70;
 }
 
 template <bool XK, bool YK>
@@ -371,6 +673,33 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
             tl = Tail{ntiles - ntail, ts, a->tail_ws};
             grid = dim3(tl.full + ntail * ts, 1);
         }
+    }
+    // 256 x 256 ping-pong kernel: large problems whose tile count fills the chip
+    const int tm2 = (a->M + T2 - 1) / T2, tn2 = (a->N + T2 - 1) / T2;
+    bool big = a->tile_mode == 2;
+    if (a->tile_mode == 0) big = use_big_tiles(a->M, a->N, a->K, tm2 * tn2 * split, num_cus());
+    if (big) {
+        const int nt2 = tm2 * tn2;
+        dim3 grid2(nt2, split);
+#define VP_GEMM2_CASE(EPI)                                                                             \
+    case EPI:                                                                                          \
+        hipLaunchKernelGGL((gemm256_kernel<XK, YK, EPI>), grid2, dim3(T2_THREADS), 0, st, X, Y, a->M, \
+                           a->N, a->K, tn2, nt2, ksplit_tiles, e);                                     \
+        break;
+        switch (a->epilogue) {
+            VP_GEMM2_CASE(VP_EPI_BF16)
+            VP_GEMM2_CASE(VP_EPI_GELU)
+            VP_GEMM2_CASE(VP_EPI_RESID_F32)
+            VP_GEMM2_CASE(VP_EPI_DGELU)
+            VP_GEMM2_CASE(VP_EPI_SPLITK_F32)
+            VP_GEMM2_CASE(VP_EPI_F32)
+            VP_GEMM2_CASE(VP_EPI_SCALE_RELU)
+            VP_GEMM2_CASE(VP_EPI_DRELU)
+            default:
+                return VP_ERR_ARG;
+        }
+#undef VP_GEMM2_CASE
+        VP_LAUNCH_RET();
     }
 #define VP_GEMM_CASE(EPI)                                                                         \
     case EPI:                                                                                     \
@@ -408,6 +737,7 @@ extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
     if (a->x_kmajor) VP_CHECK_ARG(a->M % 8 == 0 && a->M >= 8);
     if (a->y_kmajor) VP_CHECK_ARG(a->N % 8 == 0 && a->N >= 8);
     if (a->epilogue == VP_EPI_DGELU || a->epilogue == VP_EPI_DRELU) VP_CHECK_ARG(a->aux && a->ldaux % 4 == 0);
+    if (a->out2) VP_CHECK_ARG(((uintptr_t)a->out2 & 15) == 0);
     if (a->rowscale) VP_CHECK_ARG(a->rows_per_scale > 0);
     if (a->pos) VP_CHECK_ARG(a->pos_rows > 0);
     if (a->x_kmajor) return a->y_kmajor ? launch_layout<true, true>(a, stream) : launch_layout<true, false>(a, stream);

@@ -96,9 +96,10 @@ class Plan:
     def gemm(self, x, y, out, M, N, K, *, ldx, ldy, ldo, x_kmajor=False, y_kmajor=False,
              epilogue=_lib.VP_EPI_BF16, out2=None, bias=None, colscale=None, resid=None,
              rowscale=None, rows_per_scale=0, aux=None, ldaux=0, pos=None, pos_rows=0, split_k=1,
-             row_map=None, split_stride=0, tail_force=False):
+             row_map=None, split_stride=0, tail_force=False, tile_mode=0):
         a = GemmArgs()
         a.tail_force = int(tail_force)
+        a.tile_mode = int(tile_mode)
         a.split_stride = split_stride
         a.M, a.N, a.K = M, N, K
         a.x, a.ldx, a.x_kmajor = x.data_ptr(), ldx, int(x_kmajor)
@@ -119,17 +120,17 @@ class Plan:
         self._add('vp_gemm_bf16', ctypes.byref(a),
                   keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
 
-    def wgrad(self, x, y, out, M, N, K, *, ldx, ldy, split_k, slab, accumulate=False):
+    def wgrad(self, x, y, out, M, N, K, *, ldx, ldy, split_k, slab, accumulate=False, tile_mode=0):
         """out[M][N] (f32) (+)= x^T y with x [K][M], y [K][N] (both reduction-major): the weight
         gradient of a Linear / conv-as-GEMM.  The reduction over K (= tokens) is cut into
         `split_k` slices that write f32 slabs, summed by vp_splitk_reduce (deterministic)."""
         if split_k <= 1 and not accumulate:
             return self.gemm(x, y, out, M, N, K, ldx=ldx, ldy=ldy, ldo=N, x_kmajor=True, y_kmajor=True,
-                             epilogue=_lib.VP_EPI_F32)
+                             epilogue=_lib.VP_EPI_F32, tile_mode=tile_mode)
         split_k = max(1, min(split_k, K // 64))
         assert slab.numel() >= split_k * M * N
         self.gemm(x, y, slab, M, N, K, ldx=ldx, ldy=ldy, ldo=N, x_kmajor=True, y_kmajor=True,
-                  epilogue=_lib.VP_EPI_SPLITK_F32, split_k=split_k, split_stride=M * N)
+                  epilogue=_lib.VP_EPI_SPLITK_F32, split_k=split_k, split_stride=M * N, tile_mode=tile_mode)
         self._add('vp_splitk_reduce', _p(slab), split_k, M * N, M * N, _p(out), int(accumulate), keep=(slab, out))
 
     def layernorm_fwd(self, x, gamma, beta, y_bf16, y_f32, mean, rstd, M, E, eps=1e-6):
