@@ -7,95 +7,139 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // float4 chunks per lane -> E <= 2048
-
+// CH = float4 chunks per lane (row length E <= 256 * CH); the row loops are fully unrolled so the
+// register footprint follows the actual row length (E = 768 -> 3 chunks) and occupancy stays high.
+template <int CH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int E, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
     const int nch = E >> 2;
-    const float* xr = x + (size_t)row * E;
-    f32x4 v[MAXC];
-    float s = 0.f;
+    const int nwaves = gridDim.x * 4;
+    const float invE = 1.f / (float)E;
+    // affine coefficients once per wave (the wave walks several rows)
+    f32x4 g[CH], b[CH];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < CH; ++i) {
         const int c = lane + 64 * i;
-        if (c < nch) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
+        const bool ok = c < nch;
+        g[i] = ok ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b[i] = ok ? *reinterpret_cast<const f32x4*>(beta + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float mean = wave_sum(s) / (float)E;
-    float q = 0.f;
+    // two rows per iteration: twice the bytes in flight per wave
+    for (int row0 = blockIdx.x * 4 + (threadIdx.x >> 6); row0 < M; row0 += 2 * nwaves) {
+        const int row1 = row0 + nwaves;
+        const bool has1 = row1 < M;
+        const float* xr0 = x + (size_t)row0 * E;
+        const float* xr1 = x + (size_t)(has1 ? row1 : row0) * E;
+        f32x4 v0[CH], v1[CH];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < nch;
+            v0[i] = ok ? *reinterpret_cast<const f32x4*>(xr0 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v1[i] = ok ? *reinterpret_cast<const f32x4*>(xr1 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = v[i][r] - mean;
-                q += d * d;
+        for (int i = 0; i < CH; ++i) {
+            s0 += v0[i][0] + v0[i][1] + v0[i][2] + v0[i][3];
+            s1 += v1[i][0] + v1[i][1] + v1[i][2] + v1[i][3];
+        }
+        const float m0 = wave_sum(s0) * invE, m1 = wave_sum(s1) * invE;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (lane + 64 * i < nch) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d0 = v0[i][r] - m0, d1 = v1[i][r] - m1;
+                    q0 += d0 * d0;
+                    q1 += d1 * d1;
+                }
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)E + eps);
-    if (lane == 0) {
-        if (mean_out) mean_out[row] = mean;
-        if (rstd_out) rstd_out[row] = rstd;
-    }
+        const float r0 = rsqrtf(wave_sum(q0) * invE + eps), r1 = rsqrtf(wave_sum(q1) * invE + eps);
+        if (lane == 0) {
+            if (mean_out) {
+                mean_out[row0] = m0;
+                if (has1) mean_out[row1] = m1;
+            }
+            if (rstd_out) {
+                rstd_out[row0] = r0;
+                if (has1) rstd_out[row1] = r1;
+            }
+        }
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nch) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
-            f32x4 o;
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                f32x4 o0, o1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mean) * rstd * g[r] + b[r];
-            if (y) *reinterpret_cast<bf16x4*>(y + (size_t)row * E + 4 * c) = pack4(o[0], o[1], o[2], o[3]);
-            if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * E + 4 * c) = o;
+                for (int r = 0; r < 4; ++r) {
+                    o0[r] = (v0[i][r] - m0) * r0 * g[i][r] + b[i][r];
+                    o1[r] = (v1[i][r] - m1) * r1 * g[i][r] + b[i][r];
+                }
+                if (y) {
+                    *reinterpret_cast<bf16x4*>(y + (size_t)row0 * E + 4 * c) = pack4(o0[0], o0[1], o0[2], o0[3]);
+                    if (has1) *reinterpret_cast<bf16x4*>(y + (size_t)row1 * E + 4 * c) = pack4(o1[0], o1[1], o1[2], o1[3]);
+                }
+                if (y32) {
+                    *reinterpret_cast<f32x4*>(y32 + (size_t)row0 * E + 4 * c) = o0;
+                    if (has1) *reinterpret_cast<f32x4*>(y32 + (size_t)row1 * E + 4 * c) = o1;
+                }
+            }
         }
     }
 }
 
-// Backward.  Each wave walks rows w, w + W, ... and keeps per-column partial sums of
-// dgamma / dbeta / (scaled dx column sum) in registers; one LDS reduction over the
-// block's 4 waves, then the block stores its partial sums for the finalize kernel.
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+// Backward.  512-thread workgroups; each wave walks rows w, w + W, ... and keeps per-column partial
+// sums of dgamma / dbeta / (scaled dx column sum) in registers; one LDS reduction over the block's
+// 8 waves, then the block stores its partial sums for the finalize kernel.
+template <int CH>
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx, bf16* __restrict__ dxb,
                                                      const float* __restrict__ rowscale, int rows_per_scale,
                                                      float* __restrict__ partial, int M, int E) {
-    __shared__ float red[3][4][64 * 4 + 4];
+    __shared__ float red[3][8][64 * 4 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = E >> 2;
-    const int nwaves = gridDim.x * 4;
-    f32x4 ag[MAXC], ab[MAXC], ac[MAXC], g[MAXC];
+    const int nwaves = gridDim.x * 8;
+    const float invE = 1.f / (float)E;
+    f32x4 ag[CH], ab[CH], ac[CH], g[CH];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < CH; ++i) {
         ag[i] = ab[i] = ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int c = lane + 64 * i;
         g[i] = c < nch ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += nwaves) {
+    for (int row = blockIdx.x * 8 + wave; row < M; row += nwaves) {
+        // every load of the row is issued before the first use
+        f32x4 xv[CH], dr[CH];
+        bf16x4 dv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = c < nch;
+            const size_t o = (size_t)row * E + 4 * (ok ? c : 0);
+            xv[i] = *reinterpret_cast<const f32x4*>(x + o);
+            dv[i] = *reinterpret_cast<const bf16x4*>(dy + o);
+            dr[i] = dres ? *reinterpret_cast<const f32x4*>(dres + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         const float mu = mean[row], rs = rstd[row];
         const float sc = rowscale ? rowscale[row / rows_per_scale] : 1.f;
-        f32x4 xh[MAXC], gy[MAXC];
+        f32x4 xh[CH], gy[CH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * E + 4 * c);
-                const bf16x4 dv = *reinterpret_cast<const bf16x4*>(dy + (size_t)row * E + 4 * c);
+        for (int i = 0; i < CH; ++i) {
+            if (lane + 64 * i < nch) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float d = (float)dv[r];
-                    xh[i][r] = (xv[r] - mu) * rs;
+                    const float d = (float)dv[i][r];
+                    xh[i][r] = (xv[i][r] - mu) * rs;
                     gy[i][r] = d * g[i][r];
                     s1 += gy[i][r];
                     s2 += gy[i][r] * xh[i][r];
@@ -104,16 +148,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                 }
             }
         }
-        s1 = wave_sum(s1) / (float)E;
-        s2 = wave_sum(s2) / (float)E;
+        s1 = wave_sum(s1) * invE;
+        s2 = wave_sum(s2) * invE;
 #pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
+        for (int i = 0; i < CH; ++i) {
             const int c = lane + 64 * i;
             if (c < nch) {
                 f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = rs * (gy[i][r] - s1 - xh[i][r] * s2);
-                if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * E + 4 * c);
+                for (int r = 0; r < 4; ++r) o[r] = rs * (gy[i][r] - s1 - xh[i][r] * s2) + dr[i][r];
                 if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)row * E + 4 * c) = o;
                 o *= sc;
                 ac[i] += o;
@@ -123,8 +166,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     }
     // cross-wave reduction, one chunk index at a time
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        if (64 * i >= nch) break;
+    for (int i = 0; i < CH; ++i) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -133,14 +175,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             red[2][wave][lane * 4 + r] = ac[i][r];
         }
         __syncthreads();
-        // 256 threads cover the 256 columns of this chunk group
+        // threads 0-255 cover the 256 columns of this chunk group; 256-511 idle here
         const int col = threadIdx.x;            // column within the group: lane' * 4 + r
         const int c = (col >> 2) + 64 * i;      // chunk index
-        if (c < nch) {
+        if (col < 256 && c < nch) {
             const int e = 4 * c + (col & 3);
-            const float g_ = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
-            const float b_ = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
-            const float c_ = red[2][0][col] + red[2][1][col] + red[2][2][col] + red[2][3][col];
+            float g_ = 0.f, b_ = 0.f, c_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                g_ += red[0][w][col];
+                b_ += red[1][w][col];
+                c_ += red[2][w][col];
+            }
             // per-block partial sums [block][3][E]; hundreds of blocks adding atomically into the
             // same E addresses would serialise at the memory side
             float* pp = partial + (size_t)blockIdx.x * 3 * E;
@@ -151,22 +197,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     }
 }
 
-// sum the per-block partials over blocks and accumulate into dgamma / dbeta / dcolsum
+// sum the per-block partials over blocks and accumulate into dgamma / dbeta / dcolsum:
+// 16 columns x 16 block lanes per workgroup, so a 3E-column table is covered by 3E/16 workgroups
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int E,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ dcolsum) {
-    __shared__ float red[8][32];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;  // 32 columns x 8 block lanes
-    const int j = blockIdx.x * 32 + cx;                      // index into the 3E partial columns
-    float s = 0.f;
-    if (j < 3 * E)
-        for (int b = ry; b < nblocks; b += 8) s += partial[(size_t)b * 3 * E + j];
-    red[ry][cx] = s;
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + cx;                      // index into the 3E partial columns
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < 3 * E) {
+        int b = ry;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += partial[(size_t)b * 3 * E + j];
+            s1 += partial[(size_t)(b + 16) * 3 * E + j];
+            s2 += partial[(size_t)(b + 32) * 3 * E + j];
+            s3 += partial[(size_t)(b + 48) * 3 * E + j];
+        }
+        for (; b < nblocks; b += 16) s0 += partial[(size_t)b * 3 * E + j];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ry == 0 && j < 3 * E) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][cx];
+        for (int r = 0; r < 16; ++r) t += red[r][cx];
         float* dst = j < E ? dgamma : (j < 2 * E ? dbeta : dcolsum);
         if (dst) dst[j % E] += t;
     }
@@ -177,9 +232,23 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
 extern "C" int vp_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                                 float* mean, float* rstd, int M, int E, float eps, hipStream_t stream) {
     VP_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32));
-    VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * MAXC);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, y_f32,
-                       mean, rstd, M, E, eps);
+    VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * 8);
+    int blocks = (M + 7) / 8;              // 4 waves x 2 rows per pass
+    if (blocks > 1536) blocks = 1536;      // persistent: ~24 waves per CU, each walking a few rows
+#define VP_LNF(CH)                                                                                                  \
+    hipLaunchKernelGGL(ln_fwd_kernel<CH>, dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, y_f32, \
+                       mean, rstd, M, E, eps)
+    switch ((E + 255) / 256) {
+        case 1: VP_LNF(1); break;
+        case 2: VP_LNF(2); break;
+        case 3: VP_LNF(3); break;
+        case 4: VP_LNF(4); break;
+        case 5: VP_LNF(5); break;
+        case 6: VP_LNF(6); break;
+        case 7: VP_LNF(7); break;
+        default: VP_LNF(8); break;
+    }
+#undef VP_LNF
     VP_LAUNCH_RET();
 }
 
@@ -189,15 +258,27 @@ extern "C" int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float
                                 float* dcolsum, int M, int E, float* workspace, size_t workspace_floats,
                                 hipStream_t stream) {
     VP_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && (dx || dxb_bf16) && workspace);
-    VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * MAXC);
+    VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * 8);
     if (rowscale) VP_CHECK_ARG(rows_per_scale > 0);
-    int blocks = (M + 3) / 4;
+    int blocks = (M + 7) / 8;
     if (blocks > 512) blocks = 512;
     if ((size_t)blocks * 3 * E > workspace_floats) blocks = (int)(workspace_floats / (3 * (size_t)E));
     VP_CHECK_ARG(blocks >= 1);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)dy_bf16, x, mean, rstd, gamma,
-                       dres, dx, (bf16*)dxb_bf16, rowscale, rows_per_scale, workspace, M, E);
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * E + 31) / 32), dim3(256), 0, stream, workspace, blocks, E,
+#define VP_LNB(CH)                                                                                                \
+    hipLaunchKernelGGL(ln_bwd_kernel<CH>, dim3(blocks), dim3(512), 0, stream, (const bf16*)dy_bf16, x, mean, rstd, \
+                       gamma, dres, dx, (bf16*)dxb_bf16, rowscale, rows_per_scale, workspace, M, E)
+    switch ((E + 255) / 256) {
+        case 1: VP_LNB(1); break;
+        case 2: VP_LNB(2); break;
+        case 3: VP_LNB(3); break;
+        case 4: VP_LNB(4); break;
+        case 5: VP_LNB(5); break;
+        case 6: VP_LNB(6); break;
+        case 7: VP_LNB(7); break;
+        default: VP_LNB(8); break;
+    }
+#undef VP_LNB
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * E + 15) / 16), dim3(256), 0, stream, workspace, blocks, E,
                        dgamma, dbeta, dcolsum);
     VP_LAUNCH_RET();
 }

@@ -108,8 +108,9 @@ def _split_k(M, N, K, target_blocks=None):
 def _slab_elems(out_elems, K, target_blocks=None):
     """Upper bound of split_k * out_elems over outputs of at most `out_elems` elements."""
     tb = target_blocks or SPLITK_TARGET_BLOCKS
-    # split <= tb / tiles and tiles >= out_elems / 128^2  =>  split * out_elems <= tb * 128^2 (+ one slab)
-    return int(tb * 128 * 128 + out_elems)
+    # split <= tb / tiles and tiles >= out_elems / 128^2  =>  split * out_elems <= tb * 128^2 (+ one slab);
+    # the same bound with 256 x 256 tiles (tb workgroups of 65536 outputs) is 4x that
+    return int(4 * tb * 128 * 128 + out_elems)
 
 
 # =====================================================================================

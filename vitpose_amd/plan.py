@@ -4,6 +4,7 @@ beyond the foreign call itself.  Tensors are only used for memory ownership
 (torch allocates, the plan keeps them alive) and for the current HIP stream.
 """
 import ctypes
+import os
 from ctypes import c_void_p
 
 import torch
@@ -33,6 +34,23 @@ def _chk(t, dtype, name):
 
 
 _TAIL_WS = {}
+# Launch-shape choices measured once per problem signature on the device the plan is recorded on
+# (tile schedule of vp_gemm_bf16, K split of the weight-gradient GEMMs); VITPOSE_AUTOTUNE=0 disables.
+_TUNE_CACHE = {}
+AUTOTUNE = os.environ.get('VITPOSE_AUTOTUNE', '1') != '0'
+
+
+def _time_launch(fn, reps=4):
+    """Median-free quick timing: warm once, then `reps` back-to-back launches between two events."""
+    st = torch.cuda.current_stream()
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def _tail_workspace(device):
@@ -116,6 +134,20 @@ class Plan:
             tw = _tail_workspace(out.device)
             a.tail_ws, a.tail_ws_bytes = tw.data_ptr(), tw.numel() * 4
             self.keep.append(tw)
+        if AUTOTUNE and tile_mode == 0 and epilogue != _lib.VP_EPI_SPLITK_F32 and M >= 512 and N >= 256 and K >= 256:
+            key = ('gemm', M, N, K, int(x_kmajor), int(y_kmajor), epilogue, resid is not None, out2 is not None,
+                   str(out.device))
+            if key not in _TUNE_CACHE:
+                fn = self.L.vp_gemm_bf16
+                s_ = c_void_p(torch.cuda.current_stream().cuda_stream)
+                best = None
+                for mode in (1, 2):
+                    a.tile_mode = mode
+                    t = _time_launch(lambda: fn(ctypes.byref(a), s_))
+                    if best is None or t < best[0]:
+                        best = (t, mode)
+                _TUNE_CACHE[key] = best[1]
+            a.tile_mode = _TUNE_CACHE[key]
         self.tags[len(self.calls)] = (int(x_kmajor), int(y_kmajor), epilogue, M, N, K)
         self._add('vp_gemm_bf16', ctypes.byref(a),
                   keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
@@ -128,6 +160,27 @@ class Plan:
             return self.gemm(x, y, out, M, N, K, ldx=ldx, ldy=ldy, ldo=N, x_kmajor=True, y_kmajor=True,
                              epilogue=_lib.VP_EPI_F32, tile_mode=tile_mode)
         split_k = max(1, min(split_k, K // 64))
+        if AUTOTUNE and tile_mode == 0 and M >= 256 and N >= 256 and K >= 1024:
+            key = ('wgrad', M, N, K, str(out.device))
+            if key not in _TUNE_CACHE:
+                nk = K // 64
+                t256 = ((M + 255) // 256) * ((N + 255) // 256)
+                cands = {(1, split_k)}
+                for units in (256, 512):
+                    sk = max(1, min(nk, units // t256))
+                    if sk * M * N <= slab.numel():
+                        cands.add((2, sk))
+                best = None
+                for mode, sk in sorted(cands):
+                    probe = Plan()
+                    probe.gemm(x, y, slab, M, N, K, ldx=ldx, ldy=ldy, ldo=N, x_kmajor=True, y_kmajor=True,
+                               epilogue=_lib.VP_EPI_SPLITK_F32, split_k=sk, split_stride=M * N, tile_mode=mode)
+                    probe._add('vp_splitk_reduce', _p(slab), sk, M * N, M * N, _p(out), 0, keep=(slab, out))
+                    t = _time_launch(probe.run)
+                    if best is None or t < best[0]:
+                        best = (t, mode, sk)
+                _TUNE_CACHE[key] = best[1:]
+            tile_mode, split_k = _TUNE_CACHE[key]
         assert slab.numel() >= split_k * M * N
         self.gemm(x, y, slab, M, N, K, ldx=ldx, ldy=ldy, ldo=N, x_kmajor=True, y_kmajor=True,
                   epilogue=_lib.VP_EPI_SPLITK_F32, split_k=split_k, split_stride=M * N, tile_mode=tile_mode)
