@@ -443,8 +443,10 @@ def test_nchw_bridges_and_relu(dev):
 
 
 @pytest.mark.parametrize('xk,yk', [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize('M,N,K', [(512, 256, 256), (520, 264, 320), (256, 256, 64), (1024, 768, 768), (768, 512, 128)])
-def test_gemm256_layouts_exact(dev, xk, yk, M, N, K):
+@pytest.mark.parametrize('M,N,K', [(512, 256, 256), (520, 264, 320), (256, 256, 64), (1024, 768, 768), (768, 512, 128),
+                                   (384, 192, 192), (576, 392, 448)])
+@pytest.mark.parametrize('mode', [2, 3])
+def test_gemm256_layouts_exact(dev, xk, yk, M, N, K, mode):
     """The 256 x 256 ping-pong kernel (tile_mode=2): integer operands make every product and f32 sum
     exact, so any fragment / swizzle / pipeline-slot mistake (including a read of a half tile that
     has not landed) shows as a mismatch.  Partial tiles, a single K step and many K steps."""
@@ -457,11 +459,12 @@ def test_gemm256_layouts_exact(dev, xk, yk, M, N, K):
     for rep in range(3):
         out = torch.full((M, N), float('nan'), device=dev)
         run(lambda p: p.gemm(xs, ys, out, M, N, K, ldx=xs.shape[1], ldy=ys.shape[1], ldo=N, x_kmajor=xk, y_kmajor=yk,
-                             epilogue=_lib.VP_EPI_F32, tile_mode=2))
+                             epilogue=_lib.VP_EPI_F32, tile_mode=mode))
         assert torch.equal(out, ref), rep
 
 
-def test_gemm256_epilogues_and_splitk(dev):
+@pytest.mark.parametrize('mode', [2, 3])
+def test_gemm256_epilogues_and_splitk(dev, mode):
     from vitpose_amd import _lib
     M, N, K, T = 768, 512, 256, 192
     X, Y = rnd((M, K), dev, 3).bfloat16(), rnd((N, K), dev, 4, 0.1).bfloat16()
@@ -470,19 +473,19 @@ def test_gemm256_epilogues_and_splitk(dev):
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     u = torch.empty_like(out)
     run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, out2=u, epilogue=_lib.VP_EPI_GELU,
-                         tile_mode=2))
+                         tile_mode=mode))
     torch.testing.assert_close(u.float(), (acc + bias).bfloat16().float(), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(acc + bias), rtol=2e-2, atol=2e-2)
     resid = rnd((M, N), dev, 7)
     rs = torch.tensor([0.0, 1.0 / 0.7, 1.0, 2.0], device=dev)
     o32 = torch.empty(M, N, device=dev)
     run(lambda p: p.gemm(X, Y, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, resid=resid, rowscale=rs,
-                         rows_per_scale=T, epilogue=_lib.VP_EPI_RESID_F32, tile_mode=2))
+                         rows_per_scale=T, epilogue=_lib.VP_EPI_RESID_F32, tile_mode=mode))
     torch.testing.assert_close(o32, resid + rs.repeat_interleave(T)[:, None] * (acc + bias), rtol=1e-4, atol=1e-4)
     # weight gradient: both operands reduction-major, K split into slabs + deterministic reduce
     Mt = 2048
     A, Bm = ints((Mt, 512), dev, seed=8).bfloat16(), ints((Mt, 256), dev, seed=9).bfloat16()
     dw = torch.empty(512, 256, device=dev)
     slab = torch.empty(4 * 512 * 256, device=dev)
-    run(lambda p: p.wgrad(A, Bm, dw, 512, 256, Mt, ldx=512, ldy=256, split_k=4, slab=slab, tile_mode=2))
+    run(lambda p: p.wgrad(A, Bm, dw, 512, 256, Mt, ldx=512, ldy=256, split_k=4, slab=slab, tile_mode=mode))
     assert torch.equal(dw, A.float().t() @ Bm.float())

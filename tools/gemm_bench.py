@@ -20,7 +20,7 @@ def main():
     ap.add_argument('--embed', type=int, default=768)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', default='')
-    ap.add_argument('--tile-mode', type=int, default=0, help='0 heuristic, 1 = 128x128 tiles, 2 = 256x256 tiles')
+    ap.add_argument('--tile-mode', type=int, default=0, help='0 autotuned, 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = 192x192 tiles')
     ap.add_argument('--wsplit', type=int, default=0, help='override the wgrad K split')
     args = ap.parse_args()
     dev = torch.device('cuda:0')

@@ -213,19 +213,22 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
 // row-scattered stores leave the chip at ~2.5 TB/s (store-issue bound).  The wave's 64 x 64 block is
 // therefore transposed through a wave-private LDS region (row pitch 144 B: conflict-free 8-byte
 // writes, 16-byte aligned reads) and written as 16 bytes per lane, 128 contiguous bytes per row.
+// (FN = 3, 48 columns: pitch 112 B has the same properties.)  RG = row fragments staged per flush.
 constexpr int STG_PITCH = 144;
 constexpr int STG_BYTES = 64 * STG_PITCH;
 
-template <int EPI, int FM>
-__device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[FM][4], int row0, int col0, int lane,
+template <int EPI, int FM, int FN = 4, int RG = 4>
+__device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
                                                     int M, int N, char* stg) {
+    constexpr int PITCH = FN * 32 + 16, CHUNKS = FN * 2, ROWS = RG * 16;
+    static_assert(FM % RG == 0, "row fragments must split evenly into flush groups");
     static_assert(EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU || EPI == VP_EPI_DGELU ||
                   EPI == VP_EPI_DRELU, "bf16 outputs only");
     const int g = lane >> 4, li = lane & 15;
-    int col[4];
-    f32x4 bias[4], cs[4];
+    int col[FN];
+    f32x4 bias[FN], cs[FN];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < FN; ++b) {
         const int c = col0 + b * 16 + g * 4;
         col[b] = c + 3 < N ? c : N - 4;
         bias[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -234,34 +237,34 @@ __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[F
     if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
         if (e.bias) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
+            for (int b = 0; b < FN; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
         }
     }
     if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU) {
         if (e.colscale) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
+            for (int b = 0; b < FN; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
         }
     }
     constexpr int NPASS = EPI == VP_EPI_GELU ? 2 : 1;   // GELU: pass 0 = pre-activation copy (out2), pass 1 = out
 #pragma unroll
-    for (int half = 0; half < FM / 4; ++half) {
+    for (int half = 0; half < FM / RG; ++half) {
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             if (EPI == VP_EPI_GELU && pass == 0 && !e.out2) continue;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int A = half * 4 + a;
-                bf16x4 u[4];
+            for (int a = 0; a < RG; ++a) {
+                const int A = half * RG + a;
+                bf16x4 u[FN];
                 if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
                     const int row_raw = row0 + A * 16 + li;
                     const int row = row_raw < M ? row_raw : M - 1;
                     const bf16* ax = (const bf16*)e.aux + (size_t)row * e.ldaux;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) u[b] = *reinterpret_cast<const bf16x4*>(ax + col[b]);
+                    for (int b = 0; b < FN; ++b) u[b] = *reinterpret_cast<const bf16x4*>(ax + col[b]);
                 }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < FN; ++b) {
                     f32x4 v;
                     if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
                         v = acc[A][b];
@@ -281,17 +284,18 @@ __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[F
                             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                         }
                     }
-                    *reinterpret_cast<bf16x4*>(stg + (a * 16 + li) * STG_PITCH + (b * 16 + g * 4) * 2) =
+                    *reinterpret_cast<bf16x4*>(stg + (a * 16 + li) * PITCH + (b * 16 + g * 4) * 2) =
                         pack4(v[0], v[1], v[2], v[3]);
                 }
             }
             bf16* dst = (EPI == VP_EPI_GELU && pass == 0) ? (bf16*)e.out2 : (bf16*)e.out;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int id = i * 64 + lane, r = id >> 3, c = id & 7;
-                const int grow = row0 + half * 64 + r, gcol = col0 + c * 8;
-                const uint4 val = *reinterpret_cast<const uint4*>(stg + r * STG_PITCH + c * 16);
-                if (VP_ST_OK(grow < M && gcol + 7 < N)) {
+            for (int i = 0; i < (ROWS * CHUNKS + 63) / 64; ++i) {
+                const int id = i * 64 + lane, r = id / CHUNKS, c = id - r * CHUNKS;
+                const int grow = row0 + half * ROWS + r, gcol = col0 + c * 8;
+                const bool in = id < ROWS * CHUNKS;
+                const uint4 val = *reinterpret_cast<const uint4*>(stg + (in ? r * PITCH + c * 16 : 0));
+                if (VP_ST_OK(in && grow < M && gcol + 7 < N)) {
                     const size_t orow = e.row_div > 0 ? (size_t)(grow / e.row_div) * e.row_hi +
                                                             (grow % e.row_div) * e.row_lo + e.row_off
                                                       : (size_t)grow;
@@ -622,6 +626,164 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
     run_epilogue<EPI, 8, 4>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N);
 }
 
+// =====================================================================================
+// 192 x 192 x 64 tile, 512 threads, one workgroup per CU, three LDS stages
+// =====================================================================================
+// Same ping-pong schedule as the 256 x 256 kernel for problems whose extents are multiples of 192
+// but not of 256 (12288 x 768: 256 tiles = exactly one per CU).  Wave (g, wc) owns the 96 x 48
+// block at rows 96 g, columns 48 wc: 6 x 3 fragments, two phases of 18 MFMAs per K tile.
+// A K tile is six 64-row staging units (X0 X1 X2 Y0 Y1 Y2, 8 KiB each, one LDS-DMA instruction per
+// thread); with three stages every load issued during K tile u targets K tile u + 2, whose stage
+// was last read during K tile u - 1 ({X0, X1, Y0} go in phase 0 because group 1 is still reading
+// X2 one interval earlier), and ONE counted wait per K tile -- vmcnt(6) at the end of R(u,1) --
+// followed by a barrier makes K tile u + 1 visible to both groups.
+constexpr int T3 = 192, UNIT_BYTES = 64 * BK * 2, STAGE3_BYTES = 6 * UNIT_BYTES;
+
+__device__ __forceinline__ int kmaj64_key(int kr) { return ((kr >> 1) & 1) | (((kr >> 3) & 1) << 1); }
+
+template <bool KMAJ>
+__device__ __forceinline__ void stage_unit(const Operand& op, int r0, int k0, char* lds, int wave, int lane) {
+    const int base = wave * 64;
+    const int L = base + lane;       // 16-byte slot of the 8 KiB unit
+    const bf16* src;
+    if constexpr (!KMAJ) {
+        const int r = L >> 3, c = (L & 7) ^ (r & 7);
+        int row = r0 + r;
+        row = row < op.rows ? row : op.rows - 1;
+        src = op.p + (size_t)row * op.ld + k0 + c * 8;
+    } else {             // [64 k rows][64 columns], 32-byte units XOR-swizzled for the transposed read
+        const int kr = L >> 3, s16 = L & 7;
+        const int unit = (s16 >> 1) ^ kmaj64_key(kr);
+        int col = r0 + (unit * 2 + (s16 & 1)) * 8;
+        col = col <= op.rows - 8 ? col : op.rows - 8;
+        src = op.p + (size_t)(k0 + kr) * op.ld + col;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
+}
+
+// fragment `f` (16 rows / columns) of a 192-wide operand tile made of three 64-wide units
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s, int lane) {
+    const char* unit = op_units + (f >> 2) * UNIT_BYTES;
+    const int rbase = (f & 3) * 16;
+    if constexpr (!KMAJ) {
+        return read_frag<false>(unit, rbase, s, lane);
+    } else {
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, u16 = rbase >> 4;
+        const int kr0 = 32 * s + 8 * g + q, kr1 = kr0 + 4;
+        bf16x4 lo = lds_read_tr(unit + kr0 * 128 + ((u16 ^ kmaj64_key(kr0)) << 5) + (p << 3));
+        bf16x4 hi = lds_read_tr(unit + kr1 * 128 + ((u16 ^ kmaj64_key(kr1)) << 5) + (p << 3));
+        return cat8(lo, hi);
+    }
+}
+
+template <bool XKMAJ, bool YKMAJ, int EPI>
+__global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Operand Y, int M, int N, int K,
+                                                                int tiles_n, int ntiles, int ksplit_tiles, Epi e) {
+    __shared__ __attribute__((aligned(16))) char lds[3][STAGE3_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tiles_m = ntiles / tiles_n;
+    const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
+    const int gm = min(tiles_m - gid * 8, 8);
+    const int i0 = (gid * 8 + tin % gm) * T3, j0 = (tin / gm) * T3;
+    const int nk_all = K / BK;
+    const int kt0 = blockIdx.y * ksplit_tiles;
+    const int kt1 = min(nk_all, kt0 + ksplit_tiles);
+    const int nk = kt1 - kt0;
+
+    f32x4 acc[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        // unit 0-2 = X rows 0-63 / 64-127 / 128-191, 3-5 = Y columns likewise; K tile u lives in stage u % 3
+        auto stage = [&](int unit, int u, int st) {
+            const int k0 = (kt0 + (u < nk ? u : nk - 1)) * BK;
+            char* dst = lds[st] + unit * UNIT_BYTES;
+            if (unit < 3) stage_unit<XKMAJ>(X, i0 + unit * 64, k0, dst, wave, lane);
+            else stage_unit<YKMAJ>(Y, j0 + (unit - 3) * 64, k0, dst, wave, lane);
+        };
+#pragma unroll
+        for (int un = 0; un < 6; ++un) stage(un, 0, 0);
+#pragma unroll
+        for (int un = 0; un < 6; ++un) stage(un, 1, 1);
+        VP_WAIT_VM(6);
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
+
+        int cur = 0, nxt2 = 2;                        // stage of K tile u, of K tile u + 2
+#pragma unroll 1
+        for (int u = 0; u < nk; ++u) {
+            const char* lx = lds[cur];
+            const char* ly = lds[cur] + 3 * UNIT_BYTES;
+            bf16x8 xf[3][2], yf[3][2];
+            // ---- phase 0: rows 0-47 of the wave's block
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) yf[b][s] = read_frag3<YKMAJ>(ly, 3 * wc + b, s, lane);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) xf[a][s] = read_frag3<XKMAJ>(lx, 6 * grp + a, s, lane);
+            }
+            stage(0, u + 2, nxt2);
+            stage(1, u + 2, nxt2);
+            stage(3, u + 2, nxt2);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1: rows 48-95
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) xf[a][s] = read_frag3<XKMAJ>(lx, 6 * grp + 3 + a, s, lane);
+            stage(2, u + 2, nxt2);
+            stage(4, u + 2, nxt2);
+            stage(5, u + 2, nxt2);
+            VP_WAIT_VM(6);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        acc[3 + a][b] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[3 + a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();   // match group 1's extra barrier
+        VP_WAIT_VM(0);                                 // no LDS-DMA may outlive the workgroup
+    }
+    if constexpr (epi_is_bf16<EPI>()) {
+        if (((N | e.ldo) & 7) == 0) {
+            __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free for staging
+            run_epilogue_staged<EPI, 6, 3, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N,
+                                              &lds[0][0] + wave * (48 * 112));
+            return;
+        }
+    }
+    run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N);
+}
+
 inline int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -673,6 +835,29 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
             tl = Tail{ntiles - ntail, ts, a->tail_ws};
             grid = dim3(tl.full + ntail * ts, 1);
         }
+    }
+    if (a->tile_mode == 3) {
+        const int tm3 = (a->M + T3 - 1) / T3, tn3 = (a->N + T3 - 1) / T3, nt3 = tm3 * tn3;
+        dim3 grid3(nt3, split);
+#define VP_GEMM3_CASE(EPI)                                                                             \
+    case EPI:                                                                                          \
+        hipLaunchKernelGGL((gemm192_kernel<XK, YK, EPI>), grid3, dim3(T2_THREADS), 0, st, X, Y, a->M, \
+                           a->N, a->K, tn3, nt3, ksplit_tiles, e);                                     \
+        break;
+        switch (a->epilogue) {
+            VP_GEMM3_CASE(VP_EPI_BF16)
+            VP_GEMM3_CASE(VP_EPI_GELU)
+            VP_GEMM3_CASE(VP_EPI_RESID_F32)
+            VP_GEMM3_CASE(VP_EPI_DGELU)
+            VP_GEMM3_CASE(VP_EPI_SPLITK_F32)
+            VP_GEMM3_CASE(VP_EPI_F32)
+            VP_GEMM3_CASE(VP_EPI_SCALE_RELU)
+            VP_GEMM3_CASE(VP_EPI_DRELU)
+            default:
+                return VP_ERR_ARG;
+        }
+#undef VP_GEMM3_CASE
+        VP_LAUNCH_RET();
     }
     // 256 x 256 ping-pong kernel: large problems whose tile count fills the chip
     const int tm2 = (a->M + T2 - 1) / T2, tn2 = (a->N + T2 - 1) / T2;

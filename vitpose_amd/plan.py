@@ -141,7 +141,7 @@ class Plan:
                 fn = self.L.vp_gemm_bf16
                 s_ = c_void_p(torch.cuda.current_stream().cuda_stream)
                 best = None
-                for mode in (1, 2):
+                for mode in (1, 2, 3):
                     a.tile_mode = mode
                     t = _time_launch(lambda: fn(ctypes.byref(a), s_))
                     if best is None or t < best[0]:
@@ -165,11 +165,13 @@ class Plan:
             if key not in _TUNE_CACHE:
                 nk = K // 64
                 t256 = ((M + 255) // 256) * ((N + 255) // 256)
+                t192 = ((M + 191) // 192) * ((N + 191) // 192)
                 cands = {(1, split_k)}
                 for units in (256, 512):
-                    sk = max(1, min(nk, units // t256))
-                    if sk * M * N <= slab.numel():
-                        cands.add((2, sk))
+                    for mode, tiles in ((2, t256), (3, t192)):
+                        sk = max(1, min(nk, units // tiles))
+                        if sk * M * N <= slab.numel():
+                            cands.add((mode, sk))
                 best = None
                 for mode, sk in sorted(cands):
                     probe = Plan()
