@@ -63,7 +63,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int H, int E, float scale) {
     using I = Img<D>;
     __shared__ __attribute__((aligned(16))) char lds[2 * I::BYTES];
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16* __restrict
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(kimg, 16 * kt, s, lane), qf[s], sc[kt], 0, 0, 0);
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bounded look-ahead keeps the wave under 168 VGPRs
         }
         // sc[kt][r] = <q(q0+li), k(16kt+4g+r)>; softmax over keys = over kt, r and the 4 lane groups
         float m = -INFINITY;
@@ -134,19 +135,22 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16* __restrict
 
 // Backward: recompute P from the forward's log-sum-exp.  Phase A (a wave owns 16
 // queries): S, dP -> dS -> dQ.  Phase B (a wave owns 16 keys): S^T, dP^T -> P^T, dS^T
-// -> dV, dK.  Every reduction is wave-local, so nothing but the four input tiles, the
-// lse and delta vectors goes through LDS, and dq/dk/dv are written exactly once.
+// -> dV, dK.  Every reduction is wave-local, and dq/dk/dv are written exactly once.
+// Phase A needs the K, V images (its Q / dO rows are MFMA fragments read straight from global
+// memory), phase B the Q, dO images (its K / V rows likewise): the two phases share ONE pair of
+// LDS images, which keeps a workgroup at ~50 KiB so three of them run per CU and
+// their load, compute and store phases overlap (the kernel is latency-, not MFMA-bound).
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd,
+__global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16* __restrict__ dqkv, int H, int E, float scale) {
     using I = Img<D>;
-    __shared__ __attribute__((aligned(16))) char lds[4 * I::BYTES + 2 * NTOK * 4];
-    char* qimg = lds;
-    char* kimg = lds + I::BYTES;
-    char* vimg = lds + 2 * I::BYTES;
-    char* dimg = lds + 3 * I::BYTES;
-    float* s_lse = reinterpret_cast<float*>(lds + 4 * I::BYTES);
+    __shared__ __attribute__((aligned(16))) char lds[2 * I::BYTES + 2 * NTOK * 4];
+    char* kimg = lds;                 // phase A: K, V
+    char* vimg = lds + I::BYTES;
+    char* qimg = lds;                 // phase B: Q, dO (same storage)
+    char* dimg = lds + I::BYTES;
+    float* s_lse = reinterpret_cast<float*>(lds + 2 * I::BYTES);
     float* s_del = s_lse + NTOK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -154,10 +158,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16* __restrict
     const bf16* base = qkv + (size_t)b * NTOK * ld + h * D;
     const bf16* dob = dout + (size_t)b * NTOK * E + h * D;
     const bf16* ofb = o_fwd + (size_t)b * NTOK * E + h * D;
-    I::fill(qimg, base, ld, tid);
     I::fill(kimg, base + E, ld, tid);
     I::fill(vimg, base + 2 * E, ld, tid);
-    I::fill(dimg, dob, (size_t)E, tid);
     const float LOG2E = 1.44269504088896340736f;
     if (tid < NTOK) {
         float d = 0.f;
@@ -183,8 +185,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16* __restrict
         bf16x8 qf[KS], df[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qf[s] = I::rows(qimg, q0, s, lane);
-            df[s] = I::rows(dimg, q0, s, lane);
+            qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)(q0 + li) * ld + 32 * s + 8 * g);
+            df[s] = *reinterpret_cast<const bf16x8*>(dob + (size_t)(q0 + li) * E + 32 * s + 8 * g);
         }
         const float my_lse = s_lse[q0 + li], my_del = s_del[q0 + li];
         f32x4 ds[12];
@@ -198,6 +200,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16* __restrict
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(sv[r] * c - my_lse) * (pv[r] - my_del);
+            // bound the scheduler's look-ahead: hoisting all 48 fragment reads would not fit 256 VGPRs
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 o[D / 16];
 #pragma unroll
@@ -217,19 +221,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16* __restrict
     }
 
     // ---------------- phase B: dK, dV ----------------
+    __syncthreads();                  // every wave is done with the K, V images
+    I::fill(qimg, base, ld, tid);
+    I::fill(dimg, dob, (size_t)E, tid);
+    __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < 3; ++kt) {
         const int k0 = wave * 48 + kt * 16;
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            kf[s] = I::rows(kimg, k0, s, lane);
-            vf[s] = I::rows(vimg, k0, s, lane);
+            kf[s] = *reinterpret_cast<const bf16x8*>(base + E + (size_t)(k0 + li) * ld + 32 * s + 8 * g);
+            vf[s] = *reinterpret_cast<const bf16x8*>(base + 2 * E + (size_t)(k0 + li) * ld + 32 * s + 8 * g);
         }
         f32x4 dv[D / 16], dk[D / 16];
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
         for (int qs = 0; qs < 6; ++qs) {
             f32x4 pp[2], dd[2];
 #pragma unroll
