@@ -919,11 +919,12 @@ class TopDown(nn.Module):
 
     def _fused_backward(self, B, g):
         eng = self._engine
-        plan, _ = eng._train_plan(B)
+        plan, io = eng._train_plan(B)
+        # every parameter gradient is linear in the heat-map gradient the forward half left behind:
+        # seeding with the incoming dL/dloss there costs one small device op and no host sync
+        io['dheat'].mul_(g.to(io['dheat'].dtype))
         plan.run(first=eng.n_fwd_calls)
         st = eng.store
-        if not (g.numel() == 1 and float(g) == 1.0):
-            st.grad.mul_(g)
         if self._stash is not None:
             st.grad.add_(self._stash)
             self._stash = None

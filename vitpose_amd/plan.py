@@ -69,6 +69,7 @@ class Plan:
         self.tags = {}      # call index -> (x_kmajor, y_kmajor, epilogue, M, N, K) of GEMM launches
         self.use_tail_split = True
         self.timers = None  # a list: run() then brackets every GEMM launch with HIP events (see run_timed)
+        self.timer_filter = None  # optional set of (x_kmajor, y_kmajor, epilogue): only these launches are bracketed
 
     # -- replay --
     def run(self, stream=None, first=0, last=None):
@@ -92,6 +93,8 @@ class Plan:
         for i in range(first, last):
             name, fn, args = self.calls[i]
             tag = self.tags.get(i)
+            if tag is not None and self.timer_filter is not None and tag[:3] not in self.timer_filter:
+                tag = None
             if tag is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)

@@ -115,6 +115,7 @@ class PoseEngine:
                                              io['tw'] if self.use_target_weight else None, io['loss'],
                                              want_grad=True, loss_weight=self.loss_weight)
             self.n_fwd_calls = len(plan)
+            io['dheat'] = dheat
             dfeat = self.head.record_backward(plan, ws, feat, dheat, B)
             comm = self.comm
             self.vit.record_backward(plan, ws, dfeat, B, dp=io['dp'],
