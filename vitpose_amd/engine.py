@@ -272,14 +272,19 @@ class VitRunner:
             return None
 
         dx_a, dx_b = ws.f32('dx_a', M, E), ws.f32('dx_b', M, E)
-        dxb = ws.bf16('dxb', M, E)
-        du = ws.bf16('du', M, Hd)
         dxn = ws.bf16('dxn', M, E)
         dao = ws.bf16('dao', M, E)
-        dqkv = ws.bf16('dqkv', M, 3 * E)
         lnws = ws.f32('ln_bwd_partials', 3 * E * 512)
+        # The weight-gradient GEMMs (and the bias column sums) are off the critical path dx -> dx of the
+        # backward pass: they are recorded on the plan's side stream, where they fill the CUs the
+        # dependent chain leaves idle (kernel tails, HBM-bound LayerNorm / attention phases).  Their
+        # inputs (dxb, du, dqkv) therefore get one buffer per use, so the main stream never has to wait
+        # before overwriting; fork() makes the side stream wait for the producer.
+        def dxb_buf(tag):
+            return ws.bf16(f'dxb.{tag}', M, E)
         last = self.depth - 1
         x_last = ws.bufs[f'x_in.{self.depth}']
+        dxb = dxb_buf(f'{last}.mlp')
         if self.cfg.get('last_norm', True):
             plan.layernorm_bwd(dfeat, x_last, ws.bufs['mean_l'], ws.bufs['rstd_l'], self.w('last_norm.weight'),
                                None, dx_a, dxb, dp_scale(last, 1), T, self.g('last_norm.weight'),
@@ -292,47 +297,58 @@ class VitRunner:
             b = f'blocks.{i}.'
             s = f'.{i}'
             g = ws.bufs
+            du = ws.bf16('du' + s, M, Hd)
+            dqkv = ws.bf16('dqkv' + s, M, 3 * E)
             # ---- MLP branch: x_out = x_mid + s * (fc2(gelu(fc1(LN2(x_mid)))))
             # du = (dxb W2) * gelu'(u)
             plan.gemm(dxb, self.h(b + 'mlp.fc2.weight'), du, M, Hd, E, ldx=E, ldy=Hd, ldo=Hd, y_kmajor=True,
                       epilogue=_lib.VP_EPI_DGELU, aux=g['u' + s], ldaux=Hd)
-            # dW2 [E][Hd] += dxb^T h
-            plan.wgrad(dxb, g['h' + s], self.g(b + 'mlp.fc2.weight'), E, Hd, M, ldx=E, ldy=Hd,
-                       split_k=_split_k(E, Hd, M), slab=slab)
-            # dxn2 = du W1 ; dW1 [Hd][E] += du^T xn2 ; db1 = colsum(du)
+            plan.fork()
+            with plan.on_side():
+                # dW2 [E][Hd] += dxb^T h ; dW1 [Hd][E] += du^T xn2 ; db1 = colsum(du)
+                plan.wgrad(dxb, g['h' + s], self.g(b + 'mlp.fc2.weight'), E, Hd, M, ldx=E, ldy=Hd,
+                           split_k=_split_k(E, Hd, M), slab=slab)
+                plan.wgrad(du, g['xn2' + s], self.g(b + 'mlp.fc1.weight'), Hd, E, M, ldx=Hd, ldy=E,
+                           split_k=_split_k(Hd, E, M), slab=slab)
+                plan.colsum(du, self.g(b + 'mlp.fc1.bias'), M, Hd, Hd)
+            # dxn2 = du W1
             plan.gemm(du, self.h(b + 'mlp.fc1.weight'), dxn, M, E, Hd, ldx=Hd, ldy=E, ldo=E, y_kmajor=True)
-            plan.wgrad(du, g['xn2' + s], self.g(b + 'mlp.fc1.weight'), Hd, E, M, ldx=Hd, ldy=E,
-                       split_k=_split_k(Hd, E, M), slab=slab)
-            plan.colsum(du, self.g(b + 'mlp.fc1.bias'), M, Hd, Hd)
             # LN2 backward, residual add, scaled bf16 copy for the attention branch, proj bias grad
+            dxb = dxb_buf(f'{i}.attn')
             plan.layernorm_bwd(dxn, g['x_mid' + s], g['mean2' + s], g['rstd2' + s], self.w(b + 'norm2.weight'),
                                dx, other, dxb, dp_scale(i, 0), T, self.g(b + 'norm2.weight'),
                                self.g(b + 'norm2.bias'), self.g(b + 'attn.proj.bias'), M, E, workspace=lnws)
             dx, other = other, dx
             # ---- attention branch
             plan.gemm(dxb, self.h(b + 'attn.proj.weight'), dao, M, E, E, ldx=E, ldy=E, ldo=E, y_kmajor=True)
-            plan.wgrad(dxb, g['ao' + s], self.g(b + 'attn.proj.weight'), E, E, M, ldx=E, ldy=E,
-                       split_k=_split_k(E, E, M), slab=slab)
             plan.attention_bwd(g['qkv' + s], g['ao' + s], dao, g['lse' + s], dqkv, B, self.heads, self.d, T,
                                self.scale)
+            plan.fork()
+            with plan.on_side():
+                plan.wgrad(dxb, g['ao' + s], self.g(b + 'attn.proj.weight'), E, E, M, ldx=E, ldy=E,
+                           split_k=_split_k(E, E, M), slab=slab)
+                plan.wgrad(dqkv, g['xn1' + s], self.g(b + 'attn.qkv.weight'), 3 * E, E, M, ldx=3 * E, ldy=E,
+                           split_k=_split_k(3 * E, E, M), slab=slab)
+                if self.has(b + 'attn.qkv.bias'):
+                    plan.colsum(dqkv, self.g(b + 'attn.qkv.bias'), M, 3 * E, 3 * E)
             plan.gemm(dqkv, self.h(b + 'attn.qkv.weight'), dxn, M, E, 3 * E, ldx=3 * E, ldy=E, ldo=E, y_kmajor=True)
-            plan.wgrad(dqkv, g['xn1' + s], self.g(b + 'attn.qkv.weight'), 3 * E, E, M, ldx=3 * E, ldy=E,
-                       split_k=_split_k(3 * E, E, M), slab=slab)
-            if self.has(b + 'attn.qkv.bias'):
-                plan.colsum(dqkv, self.g(b + 'attn.qkv.bias'), M, 3 * E, 3 * E)
             # LN1 backward: bf16 copy is scaled for the previous block's MLP branch (or unscaled for
             # the patch embedding), its column sum is that branch's fc2 bias (or the patch bias) grad
             nxt_bias = self.g(f'blocks.{i - 1}.mlp.fc2.bias') if i > 0 else self.g('patch_embed.proj.bias')
+            dxb = dxb_buf(f'{i - 1}.mlp' if i > 0 else 'patch')
             plan.layernorm_bwd(dxn, g['x_in' + s], g['mean1' + s], g['rstd1' + s], self.w(b + 'norm1.weight'),
                                dx, other, dxb, dp_scale(i - 1, 1), T, self.g(b + 'norm1.weight'),
                                self.g(b + 'norm1.bias'), nxt_bias, M, E, workspace=lnws)
             dx, other = other, dx
             if after_block is not None and i > 0:
                 # every gradient of blocks >= i is final here except fc2.bias of block i-1
+                plan.join()
                 after_block(plan, i)
         # ---- patch embedding + position embedding
-        plan.wgrad(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
-                   split_k=_split_k(E, self.Kpe, M), slab=slab)
+        plan.fork()
+        with plan.on_side():
+            plan.wgrad(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
+                       split_k=_split_k(E, self.Kpe, M), slab=slab)
         plan.batch_sum(dx, self.dpos, B, T * E)
         gp = self.g('pos_embed')[0]
 
@@ -341,4 +357,5 @@ class VitRunner:
             gp[1:] += self.dpos
             gp[0] += self.dpos.sum(0)
         plan.host(pos_grad)
+        plan.join()
         self._dx0 = dx

@@ -70,6 +70,11 @@ class Plan:
         self.use_tail_split = True
         self.timers = None  # a list: run() then brackets every GEMM launch with HIP events (see run_timed)
         self.timer_filter = None  # optional set of (x_kmajor, y_kmajor, epilogue): only these launches are bracketed
+        # Side stream: calls recorded inside `with plan.on_side():` are launched on a second HIP stream
+        # (weight-gradient GEMMs, off the backward pass's critical path); fork() / join() order the two.
+        self.side_stream = None
+        self._side = False
+        self.side_calls = set()
 
     # -- replay --
     def run(self, stream=None, first=0, last=None):
@@ -77,9 +82,18 @@ class Plan:
         if self.timers is not None and stream is None:
             return self.run_timed(self.timers, first, last)
         s = c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
-        calls = self.calls if first == 0 and last is None else self.calls[first:last]
-        for name, fn, args in calls:
-            rc = fn(*args, s)
+        if not self.side_calls:
+            calls = self.calls if first == 0 and last is None else self.calls[first:last]
+            for name, fn, args in calls:
+                rc = fn(*args, s)
+                if rc != 0:
+                    raise KernelError(f'{name} failed with status {rc}')
+            return
+        s2 = c_void_p(self.side_stream.cuda_stream)
+        side = self.side_calls
+        for i in range(first, len(self.calls) if last is None else last):
+            name, fn, args = self.calls[i]
+            rc = fn(*args, s2 if i in side else s)
             if rc != 0:
                 raise KernelError(f'{name} failed with status {rc}')
 
@@ -87,11 +101,12 @@ class Plan:
         """Replay with a HIP event pair around every GEMM launch (events are recorded on the
         stream the kernels are launched on).  `timers` is a list that receives
         (gemm_tag, start_event, end_event); read elapsed times after a synchronize."""
-        st = torch.cuda.current_stream()
-        s = c_void_p(st.cuda_stream)
+        main = torch.cuda.current_stream()
         last = len(self.calls) if last is None else last
         for i in range(first, last):
             name, fn, args = self.calls[i]
+            st = self.side_stream if i in self.side_calls else main
+            s = c_void_p(st.cuda_stream)
             tag = self.tags.get(i)
             if tag is not None and self.timer_filter is not None and tag[:3] not in self.timer_filter:
                 tag = None
@@ -107,8 +122,50 @@ class Plan:
                 raise KernelError(f'{name} failed with status {rc}')
 
     def _add(self, name, *args, keep=()):
+        if self._side:
+            self.side_calls.add(len(self.calls))
         self.calls.append((name, getattr(self.L, name), args))
         self.keep.extend(keep)
+
+    # -- second stream --
+    def enable_side_stream(self, device):
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=device)
+        return self.side_stream
+
+    def on_side(self):
+        """Context manager: calls recorded inside go to the side stream (no-op without one)."""
+        plan = self
+
+        class _Ctx:
+            def __enter__(self_):
+                plan._side = plan.side_stream is not None
+
+            def __exit__(self_, *exc):
+                plan._side = False
+        return _Ctx()
+
+    def fork(self):
+        """Side stream waits for everything recorded so far on the main stream."""
+        if self.side_stream is None:
+            return
+        ev, side = torch.cuda.Event(), self.side_stream
+
+        def f():
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+        self.calls.append(('fork', _Host(f), ()))
+
+    def join(self):
+        """Main stream waits for everything recorded so far on the side stream."""
+        if self.side_stream is None:
+            return
+        ev, side = torch.cuda.Event(), self.side_stream
+
+        def f():
+            ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
+        self.calls.append(('join', _Host(f), ()))
 
     def __len__(self):
         return len(self.calls)
@@ -289,10 +346,18 @@ class Plan:
 
     def host(self, fn):
         """A host-side closure (tiny torch glue on the current stream) inside the plan order."""
+        if self._side:
+            side, inner = self.side_stream, fn
+
+            def fn():
+                with torch.cuda.stream(side):
+                    inner()
         self.calls.append(('host', _Host(fn), ()))
 
     def memset0(self, t):
         """Zero a tensor on the plan's stream (torch's memset: plumbing, not compute)."""
+        if self._side:
+            return self.host(t.zero_)
         self.calls.append(('zero_', _Zero(t), ()))
         self.keep.append(t)
 

@@ -4,6 +4,7 @@ Owns the flat parameter store, records one launch plan per (batch size, mode) an
 replays it.  The token-major bf16 output of the backbone's last LayerNorm is handed
 to the head as its channels-last feature map directly (no NCHW round trip).
 """
+import os
 from typing import Dict, Optional
 
 import torch
@@ -42,6 +43,8 @@ class PoseEngine:
         self.head.record_weight_prep(self.prep_derived)
         self.optimizer = None
         self.comm = None
+        # weight-gradient GEMMs on a second HIP stream (VITPOSE_SIDE_STREAM=0 keeps one stream)
+        self.side_stream_wgrad = os.environ.get('VITPOSE_SIDE_STREAM', '1') != '0'
 
     def enable_ddp(self, process_group=None, blocks_per_bucket=3):
         """Batch-sharded data parallelism: all-reduce the flat gradient buffer in buckets launched
@@ -109,6 +112,8 @@ class PoseEngine:
                       loss=ws.f32('loss', 1), dp=ws.f32('dp', self.vit.depth, 2, B))
             io['dp'].fill_(1.0)
             plan = Plan()
+            if self.side_stream_wgrad:
+                plan.enable_side_stream(self.device)
             plan.memset0(self.store.grad)
             feat = self.vit.record_forward(plan, ws, io['img'], B, training=True, dp=io['dp'])
             dheat = self.head.record_forward(plan, ws, feat, B, True, io['heat'], io['target'],
