@@ -36,6 +36,8 @@ MODELS = {
               fwd_gflop=37.05),
     'L': dict(embed_dim=1024, depth=24, num_heads=16, drop_path_rate=0.5, layer_decay=0.8, train_gflop=369.11,
               fwd_gflop=123.14),
+    'H': dict(embed_dim=1280, depth=32, num_heads=16, drop_path_rate=0.55, layer_decay=0.85, train_gflop=754.60,
+              fwd_gflop=251.66),
 }
 EPI_NAMES = {0: 'VP_EPI_BF16', 1: 'VP_EPI_GELU', 2: 'VP_EPI_RESID_F32', 3: 'VP_EPI_DGELU', 4: 'VP_EPI_SPLITK_F32',
              5: 'VP_EPI_F32', 6: 'VP_EPI_SCALE_RELU', 7: 'VP_EPI_DRELU'}

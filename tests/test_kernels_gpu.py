@@ -161,7 +161,7 @@ def _attn_ref(qkv, B, H, d, scale):
     return (p @ v).transpose(1, 2).reshape(B * T, H * d), torch.logsumexp(s, -1).reshape(B * H, T)
 
 
-@pytest.mark.parametrize('H,d', [(2, 32), (3, 64), (12, 64)])
+@pytest.mark.parametrize('H,d', [(2, 32), (3, 64), (12, 64), (2, 80), (16, 80)])
 def test_attention_fwd_bwd(dev, H, d):
     B, T, E = 2, 192, H * d
     qkv = (rnd((B * T, 3 * E), dev, 1) * 1.5).bfloat16()

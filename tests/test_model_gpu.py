@@ -234,3 +234,27 @@ def test_simple_decoder_train_step_vs_oracle(dev):
         assert relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0] < 5e-2, n
     for n in ('blocks.1.mlp.fc2.weight', 'blocks.0.attn.qkv.weight', 'patch_embed.proj.weight', 'pos_embed'):
         assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 8e-2, n
+
+
+@pytest.mark.parametrize('name', ['L', 'H'])
+def test_large_and_huge_widths_one_block_train_step(dev, name):
+    """ViTPose-L / -H widths (E 1024 / 1280, head_dim 64 / 80) through one block + classic head,
+    forward and backward, against the oracle (whose block arithmetic at these widths is pinned by
+    tests/golden/block_widths.npz)."""
+    vcfg = O.vit_cfg(name, depth=1, drop_path_rate=0.0)
+    hc = O.classic_head_cfg(vcfg['embed_dim'])
+    bb, hd = O.synth_vit_weights(vcfg, seed=40), O.synth_head_weights(hc, seed=41)
+    eng = make_engine(vcfg, hc, bb, hd, dev)
+    img, target, tw = O.synth_batch(2, seed=42)
+    loss, heat = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+    torch.cuda.synchronize()
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    hdr = {k: v.clone() for k, v in hd.items()}
+    ref = O.head_forward(hdr, O.vit_forward(bbr, img, vcfg), hc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
+    for n in ('blocks.0.attn.qkv.weight', 'blocks.0.attn.proj.weight', 'blocks.0.mlp.fc1.weight', 'blocks.0.norm1.weight',
+              'patch_embed.proj.weight'):
+        assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 0.1, n

@@ -21,19 +21,74 @@ constexpr int NTOK = 192;
 // One LDS image serves ds_read_b128 row reads and ds_read_b64_tr_b16 transposed
 // reads: rows of D bf16, 32-byte units XOR-swizzled by a row key so that both the 8
 // rows of a transposed read and the 16 rows of a row read fall on distinct banks.
+// A reduction over the head dimension runs ceil(D/32) steps of the 16x16x32 MFMA.  When D % 32 == 16
+// (head_dim 80, ViTPose-H) the last step carries 16 real columns in lane groups 0-1 and zeros in
+// groups 2-3 of BOTH operands.  (A 16x16x16 MFMA for that tail, chained on the accumulator of a
+// 16x16x32 MFMA issued just before it, returned stale values in half of the accumulator rows on
+// gfx950 / ROCm 7.2; one opcode per accumulation chain avoids the mixed-shape dependency.)
+template <int D>
+struct Frag {
+    static constexpr int NS = (D + 31) / 32;
+    bf16x8 f[NS];
+};
+
+template <int D>
+__device__ __forceinline__ f32x4 mfma_d(const Frag<D>& a, const Frag<D>& b, f32x4 acc) {
+#pragma unroll
+    for (int s = 0; s < Frag<D>::NS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.f[s], b.f[s], acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+    return z;
+}
+
+// 16 rows of a [rows][ld] bf16 matrix in global memory as an MFMA operand (lane -> row li, k = 8g..8g+7)
+template <int D>
+__device__ __forceinline__ Frag<D> frag_global(const bf16* row_li, int g) {
+    Frag<D> r;
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) r.f[s] = *reinterpret_cast<const bf16x8*>(row_li + 32 * s + 8 * g);
+    if constexpr (D % 32 == 16) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(row_li + (D - 16) + 8 * (g & 1));
+        r.f[D / 32] = g < 2 ? v : zero8();
+    }
+    return r;
+}
+
 template <int D>
 struct Img {
-    static constexpr int P = D * 2;          // row pitch in bytes
+    // power-of-two head dims: rows of D bf16 with 32-byte units XOR-swizzled by a row key.
+    // D = 80: 160-byte rows padded to a 176-byte pitch (44 dwords: 16 consecutive rows start on 16
+    // distinct bank quads, so row reads are conflict-free without a swizzle).
+    static constexpr bool POW2 = (D & (D - 1)) == 0;
+    static constexpr int P = POW2 ? D * 2 : D * 2 + 16;   // row pitch in bytes
     static constexpr int U = D / 16;         // 32-byte units per row
-    static constexpr int R = 256 / P;        // rows per 256-byte bank row
+    static constexpr int R = POW2 ? 256 / P : 1;          // rows per 256-byte bank row
     static constexpr int BYTES = NTOK * P;
-    __device__ static __forceinline__ int key(int row) { return (row / R) % U; }
+    __device__ static __forceinline__ int key(int row) { return POW2 ? (row / R) % U : 0; }
     __device__ static __forceinline__ int off16(int row, int c16) {  // 16-byte chunk c16 of a row
         return row * P + ((((c16 >> 1) ^ key(row)) << 5) | ((c16 & 1) << 4));
     }
     // row-read fragment: rows [r0, r0+16), reduction step s (32 wide): lane -> row r0+li, chunk 4s+g
     __device__ static __forceinline__ bf16x8 rows(const char* img, int r0, int s, int lane) {
         return *reinterpret_cast<const bf16x8*>(img + off16(r0 + (lane & 15), 4 * s + (lane >> 4)));
+    }
+    // all reduction steps of rows [r0, r0+16)
+    __device__ static __forceinline__ Frag<D> frag(const char* img, int r0, int lane) {
+        Frag<D> r;
+#pragma unroll
+        for (int s = 0; s < D / 32; ++s) r.f[s] = rows(img, r0, s, lane);
+        if constexpr (D % 32 == 16) {
+            const int g = lane >> 4;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + off16(r0 + (lane & 15), (D - 16) / 8 + (g & 1)));
+            r.f[D / 32] = g < 2 ? v : zero8();
+        }
+        return r;
     }
     // transposed fragment for the reduction over ROWS: 32-row step rs, 16-column unit dt.
     // element 4h+e of lane (g, li) = img[32 rs + 16 h + 4 g + e][16 dt + li]
@@ -63,7 +118,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(256, (D & (D - 1)) == 0 ? 3 : 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int H, int E, float scale) {
     using I = Img<D>;
     __shared__ __attribute__((aligned(16))) char lds[2 * I::BYTES];
@@ -77,21 +132,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict
     I::fill(vimg, base + 2 * E, ld, tid);
     __syncthreads();
     const float c = scale * 1.44269504088896340736f;
-    constexpr int KS = D / 32;
 #pragma unroll 1
     for (int qt = 0; qt < 3; ++qt) {
         const int q0 = wave * 48 + qt * 16;
-        bf16x8 qf[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)(q0 + li) * ld + 32 * s + 8 * g);
+        const Frag<D> qf = frag_global<D>(base + (size_t)(q0 + li) * ld, g);
         f32x4 sc[12];
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt) {
-            sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(kimg, 16 * kt, s, lane), qf[s], sc[kt], 0, 0, 0);
+            sc[kt] = mfma_d<D>(I::frag(kimg, 16 * kt, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});
             if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bounded look-ahead keeps the wave under 168 VGPRs
         }
         // sc[kt][r] = <q(q0+li), k(16kt+4g+r)>; softmax over keys = over kt, r and the 4 lane groups
@@ -141,7 +189,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16* __restrict
 // LDS images, which keeps a workgroup at ~50 KiB so three of them run per CU and
 // their load, compute and store phases overlap (the kernel is latency-, not MFMA-bound).
 template <int D>
-__global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd,
+__global__ __launch_bounds__(256, (D & (D - 1)) == 0 ? 3 : 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16* __restrict__ dqkv, int H, int E, float scale) {
     using I = Img<D>;
@@ -175,29 +223,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict
     }
     __syncthreads();
     const float c = scale * LOG2E;
-    constexpr int KS = D / 32;
     bf16* dq_base = dqkv + (size_t)b * NTOK * ld + h * D;
 
     // ---------------- phase A: dQ ----------------
 #pragma unroll 1
     for (int qt = 0; qt < 3; ++qt) {
         const int q0 = wave * 48 + qt * 16;
-        bf16x8 qf[KS], df[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)(q0 + li) * ld + 32 * s + 8 * g);
-            df[s] = *reinterpret_cast<const bf16x8*>(dob + (size_t)(q0 + li) * E + 32 * s + 8 * g);
-        }
+        const Frag<D> qf = frag_global<D>(base + (size_t)(q0 + li) * ld, g);
+        const Frag<D> df = frag_global<D>(dob + (size_t)(q0 + li) * E, g);
         const float my_lse = s_lse[q0 + li], my_del = s_del[q0 + li];
         f32x4 ds[12];
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt) {
-            f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, pv = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(kimg, 16 * kt, s, lane), qf[s], sv, 0, 0, 0);
-                pv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(vimg, 16 * kt, s, lane), df[s], pv, 0, 0, 0);
-            }
+            const f32x4 sv = mfma_d<D>(I::frag(kimg, 16 * kt, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+            const f32x4 pv = mfma_d<D>(I::frag(vimg, 16 * kt, lane), df, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(sv[r] * c - my_lse) * (pv[r] - my_del);
             // bound the scheduler's look-ahead: hoisting all 48 fragment reads would not fit 256 VGPRs
@@ -228,12 +267,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict
 #pragma unroll 1
     for (int kt = 0; kt < 3; ++kt) {
         const int k0 = wave * 48 + kt * 16;
-        bf16x8 kf[KS], vf[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            kf[s] = *reinterpret_cast<const bf16x8*>(base + E + (size_t)(k0 + li) * ld + 32 * s + 8 * g);
-            vf[s] = *reinterpret_cast<const bf16x8*>(base + 2 * E + (size_t)(k0 + li) * ld + 32 * s + 8 * g);
-        }
+        const Frag<D> kf = frag_global<D>(base + E + (size_t)(k0 + li) * ld, g);
+        const Frag<D> vf = frag_global<D>(base + 2 * E + (size_t)(k0 + li) * ld, g);
         f32x4 dv[D / 16], dk[D / 16];
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -243,12 +278,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int qt = 2 * qs + hh;
-                f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, pv = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(qimg, 16 * qt, s, lane), kf[s], sv, 0, 0, 0);
-                    pv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::rows(dimg, 16 * qt, s, lane), vf[s], pv, 0, 0, 0);
-                }
+                const f32x4 sv = mfma_d<D>(I::frag(qimg, 16 * qt, lane), kf, f32x4{0.f, 0.f, 0.f, 0.f});
+                const f32x4 pv = mfma_d<D>(I::frag(dimg, 16 * qt, lane), vf, f32x4{0.f, 0.f, 0.f, 0.f});
                 // sv[r] = <q(16qt+4g+r), k(k0+li)>
                 const f32x4 ls = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
                 const f32x4 dl = *reinterpret_cast<const f32x4*>(s_del + 16 * qt + 4 * g);
@@ -287,6 +318,7 @@ extern "C" int vp_attention_fwd(const void* qkv, void* out, float* lse, int B, i
     switch (head_dim) {
         case 32: hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, stream, (const bf16*)qkv, (bf16*)out, lse, H, E, scale); break;
         case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, stream, (const bf16*)qkv, (bf16*)out, lse, H, E, scale); break;
+        case 80: hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, block, 0, stream, (const bf16*)qkv, (bf16*)out, lse, H, E, scale); break;
         default: return VP_ERR_UNSUPPORTED;
     }
     VP_LAUNCH_RET();
@@ -301,6 +333,7 @@ extern "C" int vp_attention_bwd(const void* qkv, const void* out_fwd, const void
     switch (head_dim) {
         case 32: hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, 0, stream, (const bf16*)qkv, (const bf16*)out_fwd, (const bf16*)dout, lse, (bf16*)dqkv, H, E, scale); break;
         case 64: hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, 0, stream, (const bf16*)qkv, (const bf16*)out_fwd, (const bf16*)dout, lse, (bf16*)dqkv, H, E, scale); break;
+        case 80: hipLaunchKernelGGL(attn_bwd_kernel<80>, grid, block, 0, stream, (const bf16*)qkv, (const bf16*)out_fwd, (const bf16*)dout, lse, (bf16*)dqkv, H, E, scale); break;
         default: return VP_ERR_UNSUPPORTED;
     }
     VP_LAUNCH_RET();

@@ -166,9 +166,9 @@ class VitRunner:
         self.Kpe = self.C * self.patch * self.patch
         if self.T + 1 != store.shapes[prefix + 'pos_embed'][1]:
             raise ValueError('pos_embed length does not match the patch grid')
-        if self.T != 192 or self.d not in (32, 64):
+        if self.T != 192 or self.d not in (32, 64, 80):
             raise NotImplementedError(
-                f'attention kernel covers 192 tokens and head_dim 32/64 (got {self.T}, {self.d})')
+                f'attention kernel covers 192 tokens and head_dim 32/64/80 (got {self.T}, {self.d})')
         if self.E % 64 or self.hidden % 64 or self.Kpe % 64:
             raise NotImplementedError('channel counts must be multiples of 64')
         dev = store.device
