@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; one counter
+per run) of `bench.py`:
+
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_FETCH_SIZE -o pmc -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_WRITE_SIZE -o pmc -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline
+  python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv \
+                              gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv profiles/pmc_traffic.json
+
+Units and corrections: both counters are reported in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte
+requests of wide coalesced reads (16 B per lane, plain loads and LDS-DMA alike) at 64 bytes, i.e. it
+reports one half of the bytes: fetch bytes = 2 x FETCH_SIZE x 1024.  WRITE_SIZE is exact for
+16-byte-per-lane stores: write bytes = WRITE_SIZE x 1024.  Other access widths are uncalibrated.
+The launcher vp_gemm_bf16 picks one of three tile-schedule kernels per shape; rows are keyed both by
+the device kernel name and by the launcher instantiation vp_gemm_bf16<x_kmajor, y_kmajor, epilogue>."""
+import csv
+import json
+import re
+import sys
+
+
+def load(path):
+    agg = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            d = agg.setdefault(r['Kernel_Name'], [0, 0.0])
+            d[0] += 1
+            d[1] += float(r['Counter_Value'])
+    return agg
+
+
+def main():
+    fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    res = {}
+    groups = {}
+    for name in sorted(set(fetch) | set(write)):
+        nf, kf = fetch.get(name, [0, 0.0])
+        nw, kw = write.get(name, [0, 0.0])
+        n = max(nf, nw)
+        if n == 0:
+            continue
+        fb = 2.0 * kf * 1024 / max(nf, 1)
+        wb = kw * 1024 / max(nw, 1)
+        short = re.sub(r'\(anonymous namespace\)::', '', name)
+        short = re.sub(r'\(.*$', '', short).replace('void ', '')
+        res[short] = dict(launches=n, fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
+                          hbm_bytes_per_launch=round(fb + wb))
+        m = re.match(r'gemm(?:192|256)?_kernel<(true|false), (true|false), (\d+)>', short)
+        if m:
+            g = groups.setdefault(f'vp_gemm_bf16<{m.group(1)}, {m.group(2)}, {m.group(3)}>', [0, 0.0, 0.0])
+            g[0] += n
+            g[1] += fb * n
+            g[2] += wb * n
+    for k, (n, fb, wb) in groups.items():
+        res[k] = dict(launches=n, fetch_bytes_per_launch=round(fb / n), write_bytes_per_launch=round(wb / n),
+                      hbm_bytes_per_launch=round((fb + wb) / n))
+    json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
+    for k in sorted(res, key=lambda k: -res[k]['hbm_bytes_per_launch'] * res[k]['launches'])[:16]:
+        v = res[k]
+        print(f"{k[:70]:70s} x{v['launches']:5d}  fetch {v['fetch_bytes_per_launch'] / 1e6:8.1f} MB  write "
+              f"{v['write_bytes_per_launch'] / 1e6:8.1f} MB")
+
+
+if __name__ == '__main__':
+    main()
