@@ -184,6 +184,27 @@ int vp_relu_bf16(const void* x, void* y, size_t n, vp_stream_t stream);
  * head fed by a foreign NCHW backbone, and of NCHW heat-map gradients (vit.py:330 is the inverse). */
 int vp_nchw_to_cl_bf16(const float* src, void* dst_bf16, int B, int C, int HW, int ld, vp_stream_t stream);
 
+/* ----------------------------------------------------- fp32-accurate path ----------
+ * Evaluation at the reference's fp32 accuracy (the 1e-3 max-abs heat-map tolerance on arbitrary
+ * weights): every GEMM operand is a pair of bf16 arrays hi = bf16(x), lo = bf16(x - hi) and a
+ * Linear / conv product is three vp_gemm_bf16 launches (hi*hi + hi*lo + lo*hi, chained through
+ * VP_EPI_F32 / VP_EPI_RESID_F32); everything else runs in f32:
+ *   vp_finish_f32: y = act(x * colscale + colshift) * rowscale[row / rows_per_scale] + resid, act 0 none /
+ *     1 exact-erf GELU / 2 ReLU (bias, nn.GELU vit.py:67, BatchNorm + ReLU simple_head.py:333-334, residual
+ *     vit.py:138-139); written as f32 `out` and / or the bf16 pair hi / lo (ld = ldo), rows optionally remapped
+ *     (row_map = {div, hi, lo, off} as in vp_gemm_args, NULL = identity);
+ *   vp_split_f32: hi / lo (and the f32 remainder x - hi) of a flat buffer (weights);
+ *   vp_attention_f32: Attention.forward core (vit.py:102-111) on packed f32 qkv, f32 softmax, f32 out;
+ *   vp_patch_im2col_split: vp_patch_im2col with the hi / lo split of the pixels. */
+int vp_finish_f32(const float* x, int ldx, const float* colscale, const float* colshift, int act,
+                  const float* resid, int ldr, const float* rowscale, int rows_per_scale, float* out,
+                  void* hi_bf16, void* lo_bf16, int ldo, int M, int N, const int row_map[4], vp_stream_t stream);
+int vp_split_f32(const float* x, void* hi_bf16, void* lo_bf16, float* lo_f32, size_t n, vp_stream_t stream);
+int vp_attention_f32(const float* qkv, float* out, int B, int H, int head_dim, int tokens, float scale,
+                     vp_stream_t stream);
+int vp_patch_im2col_split(const float* img, void* col_hi_bf16, void* col_lo_bf16, int B, int C, int H, int W,
+                          int patch, int stride, int pad, vp_stream_t stream);
+
 /* ------------------------------------------------------------------ Loss --------
  * JointsMSELoss.forward (mmpose/models/losses/mse_loss.py:24-44) fused with its gradient and the
  * channels-last -> NCHW copy of the heatmaps.  heat [B*HW][ldh] f32 (first K columns valid);

@@ -489,3 +489,70 @@ def test_gemm256_epilogues_and_splitk(dev, mode):
     slab = torch.empty(4 * 512 * 256, device=dev)
     run(lambda p: p.wgrad(A, Bm, dw, 512, 256, Mt, ldx=512, ldy=256, split_k=4, slab=slab, tile_mode=mode))
     assert torch.equal(dw, A.float().t() @ Bm.float())
+
+
+# ------------------------------------------------------------------ fp32-accurate path
+def test_split_and_gemm3_reach_fp32_accuracy(dev):
+    """hi / lo split is exact to ~2^-17 and the three-GEMM product is ~1e-5 from an fp64 product
+    (a single bf16 GEMM is ~4e-3)."""
+    M, N, K = 384, 256, 768
+    x, w, bias = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.05), rnd((N,), dev, 3)
+    xh, xl = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+    wh, wl = torch.empty_like(w, dtype=torch.bfloat16), torch.empty_like(w, dtype=torch.bfloat16)
+    wlf = torch.empty_like(w)
+    acc = torch.full((M, N), float('nan'), device=dev)
+
+    def build(p):
+        p.split_f32(x, xh, xl, None, M * K)
+        p.split_f32(w, wh, wl, wlf, N * K)
+        p.gemm3(xh, xl, wh, wl, acc, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias)
+    run(build)
+    assert torch.equal(xh, x.bfloat16()) and torch.equal(wlf, w - wh.float())
+    assert torch.equal(xl, (x - xh.float()).bfloat16())
+    assert (x - xh.float() - xl.float()).abs().max() <= x.abs().max() * 2 ** -16
+    ref = (x.double() @ w.double().t() + bias.double()).float()
+    err = (acc - ref).abs().max().item()
+    one = (xh.float() @ wh.float().t() + bias - ref).abs().max().item()
+    assert err < 2e-4 * ref.abs().max().item() and err < one / 50, (err, one)
+
+
+def test_finish_f32_variants(dev):
+    M, N = 384, 256
+    x, cs, sh, res = rnd((M, N), dev, 1), rnd((N,), dev, 2), rnd((N,), dev, 3), rnd((M, N), dev, 4)
+    rs = torch.rand(2, device=dev) + 0.5
+    out = torch.empty(M, N, device=dev)
+    hi = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    run(lambda p: p.finish_f32(x, M, N, ldx=N, ldo=N, out=out, hi=hi, lo=lo, colscale=cs, colshift=sh, act=1,
+                               resid=res, ldr=N, rowscale=rs, rows_per_scale=192))
+    ref = torch.nn.functional.gelu(x * cs + sh) * rs.repeat_interleave(192)[:, None] + res
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(hi, out.bfloat16()) and torch.equal(lo, (out - hi.float()).bfloat16())
+    # ReLU + sub-pixel row remap (phase (1, 0) of a 2x up-sampled 4 x 3 grid, batch 2)
+    B, H, W = 2, 4, 3
+    z = rnd((B * H * W, 64), dev, 5)
+    full = torch.zeros(B * 4 * H * W, 64, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.finish_f32(z, B * H * W, 64, ldx=64, ldo=64, hi=full, act=2, row_map=(W, 4 * W, 2, 2 * W)))
+    want = torch.zeros(B, 2 * H, 2 * W, 64, device=dev)
+    want[:, 1::2, 0::2] = z.relu().view(B, H, W, 64)
+    assert torch.equal(full.view(B, 2 * H, 2 * W, 64).float(), want.bfloat16().float())
+
+
+@pytest.mark.parametrize('H,d', [(2, 32), (6, 64), (2, 80)])
+def test_attention_f32(dev, H, d):
+    B, T, E = 2, 192, H * d
+    qkv = rnd((B * T, 3 * E), dev, 1) * 1.5
+    out = torch.empty(B * T, E, device=dev)
+    run(lambda p: p.attention_f32(qkv, out, B, H, d, T, d ** -0.5))
+    ref, _ = _attn_ref(qkv.double(), B, H, d, d ** -0.5)
+    torch.testing.assert_close(out, ref.float(), rtol=1e-5, atol=1e-5)
+
+
+def test_patch_im2col_split(dev):
+    B = 2
+    img = rnd((B, 3, 256, 192), dev, 1)
+    ch = torch.empty(B * 192, 768, device=dev, dtype=torch.bfloat16)
+    cl = torch.empty_like(ch)
+    run(lambda p: p.patch_im2col_split(img, ch, cl, B, 3, 256, 192, 16, 16, 2))
+    ref = torch.nn.functional.unfold(img, 16, padding=2, stride=16).transpose(1, 2).reshape(B * 192, 768)
+    assert torch.equal(ch, ref.bfloat16()) and torch.equal(cl, (ref - ch.float()).bfloat16())

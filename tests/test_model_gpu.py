@@ -258,3 +258,51 @@ def test_large_and_huge_widths_one_block_train_step(dev, name):
     for n in ('blocks.0.attn.qkv.weight', 'blocks.0.attn.proj.weight', 'blocks.0.mlp.fc1.weight', 'blocks.0.norm1.weight',
               'patch_embed.proj.weight'):
         assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 0.1, n
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32-accurate evaluation: the 1e-3 max-abs heat-map tolerance on NON-degenerate weights
+# (O(1) heat maps), against the vectors the reference's own source produced.
+# ---------------------------------------------------------------------------------------------
+EXACT_TOL = 1e-3   # max-abs on heat maps, the tolerance the headline configuration states
+
+
+def test_exact_eval_classic_vs_reference_golden_1e3(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'vitpose_s_classic_eval.npz'))
+    vcfg, hc = O.vit_cfg('S'), O.classic_head_cfg(384)
+    eng = make_engine(vcfg, hc, O.synth_vit_weights(vcfg, seed=20), O.synth_head_weights(hc, seed=21), dev)
+    img, _, _ = O.synth_batch(2, seed=22)
+    heat = eng.infer(img.to(dev), exact=True).cpu()
+    rel, mx = relerr(heat, g['heat'])
+    print(f'exact eval, classic head, |ref|max {np.abs(g["heat"]).max():.2f}: rel {rel:.2e} maxabs {mx:.2e}')
+    assert mx < EXACT_TOL, (rel, mx)
+    # the bf16 plan of the same engine still works afterwards and is the looser one
+    heat_b = eng.infer(img.to(dev)).cpu()
+    assert relerr(heat_b, g['heat'])[1] > mx
+
+
+def test_exact_eval_simple_decoder_vs_reference_golden_1e3(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'vitpose_s_simple_eval.npz'))
+    vcfg, hs = O.vit_cfg('S'), O.simple_head_cfg(384)
+    eng = make_engine(vcfg, hs, O.synth_vit_weights(vcfg, seed=20), O.synth_head_weights(hs, seed=23), dev)
+    img, _, _ = O.synth_batch(2, seed=22)
+    heat = eng.infer(img[:1].to(dev), exact=True).cpu()
+    rel, mx = relerr(heat, g['heat'])
+    print(f'exact eval, simple decoder, |ref|max {np.abs(g["heat"]).max():.2f}: rel {rel:.2e} maxabs {mx:.2e}')
+    assert mx < EXACT_TOL, (rel, mx)
+
+
+@pytest.mark.parametrize('name', ['B', 'H'])
+def test_exact_eval_wide_models_vs_oracle_1e3(dev, name):
+    """ViTPose-B (head_dim 64) and -H widths (head_dim 80), two blocks, against the oracle."""
+    vcfg = O.vit_cfg(name, depth=2, drop_path_rate=0.0)
+    hc = O.classic_head_cfg(vcfg['embed_dim'])
+    bb, hd = O.synth_vit_weights(vcfg, seed=50), O.synth_head_weights(hc, seed=51)
+    eng = make_engine(vcfg, hc, bb, hd, dev)
+    img, _, _ = O.synth_batch(3, seed=52)
+    heat = eng.infer(img.to(dev), exact=True).cpu()
+    with torch.no_grad():
+        ref = O.topdown_forward(bb, hd, img, vcfg, hc)
+    rel, mx = relerr(heat, ref)
+    print(f'exact eval ViTPose-{name} (2 blocks), |ref|max {ref.abs().max():.2f}: rel {rel:.2e} maxabs {mx:.2e}')
+    assert mx < EXACT_TOL * max(1.0, ref.abs().max().item()), (rel, mx)

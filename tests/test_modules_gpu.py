@@ -249,6 +249,31 @@ def test_topdown_forward_test_flip_and_decode(dev, golden_dir):
     assert rel(d, g1['heat']) < 3e-2
 
 
+def test_topdown_forward_test_fp32_exact_1e3(dev, golden_dir):
+    """The same flip-test call with test_cfg['fp32_exact']: averaged heat maps within 1e-3 max-abs of the
+    reference's fp32 CPU result on O(1) heat maps, and forward_dummy likewise."""
+    from vitpose_amd.builder import build_posenet
+    g3 = np.load(os.path.join(golden_dir, 'vitpose_s_classic_fliptest.npz'))
+    g1 = np.load(os.path.join(golden_dir, 'vitpose_s_classic_eval.npz'))
+    vcfg, hc = O.vit_cfg('S'), O.classic_head_cfg(384)
+    m = build_posenet(dict(type='TopDown', backbone=dict(vcfg, type='ViT'),
+                           keypoint_head=dict(hc, type='TopdownHeatmapSimpleHead', loss_keypoint=dict(LOSS)),
+                           train_cfg=dict(), test_cfg=dict(flip_test=True, post_process='default',
+                                                           shift_heatmap=False, use_udp=False, fp32_exact=True)))
+    sd = {'backbone.' + k: v for k, v in O.synth_vit_weights(vcfg, seed=20).items()}
+    sd.update({'keypoint_head.' + k: v for k, v in O.synth_head_weights(hc, seed=21).items()})
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    img, _, _ = O.synth_batch(2, seed=22)
+    metas = [dict(center=np.array([100., 120.]), scale=np.array([1.2, 1.6]), image_file=f'{i}.jpg', bbox_id=i,
+                  flip_pairs=PAIRS, bbox_score=0.9) for i in range(2)]
+    res = m(img=img.to(dev), img_metas=metas, return_loss=False, return_heatmap=True)
+    assert np.abs(res['output_heatmap'] - g3['heat']).max() < 1e-3
+    with torch.no_grad():
+        d = m.forward_dummy(img.to(dev))
+    assert (d.cpu() - torch.as_tensor(g1['heat'])).abs().max().item() < 1e-3
+
+
 def test_torch_optimizer_and_state_dict_roundtrip(dev):
     """The parameters are ordinary nn.Parameters: a stock torch optimizer can step them (its in-place
     update is picked up by the next forward), and state_dict()/load_state_dict() round-trip."""

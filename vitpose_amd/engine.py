@@ -43,6 +43,14 @@ class ParamStore:
         self.half = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
         self.exp_avg = None
         self.exp_avg_sq = None
+        # fp32-accurate evaluation: remainder data - float(half), as f32 and rounded to bf16 (on demand)
+        self.data_lo = None
+        self.half_lo = None
+
+    def ensure_lo(self):
+        if self.half_lo is None:
+            self.data_lo = torch.zeros_like(self.data)
+            self.half_lo = torch.zeros_like(self.half)
 
     def _v(self, buf, name):
         o = self.offsets[name]
@@ -57,6 +65,12 @@ class ParamStore:
 
     def hview(self, name):
         return self._v(self.half, name)
+
+    def lview(self, name):
+        return self._v(self.half_lo, name)
+
+    def lfview(self, name):
+        return self._v(self.data_lo, name)
 
     def load(self, sd: Dict[str, torch.Tensor], strict=True):
         for n in self.names:
@@ -257,6 +271,58 @@ class VitRunner:
             if tokens_f32 is not None:
                 plan.strided_cast(x, tokens_f32, (1, 1, 1, M * E), (0, 0, 0, 1))
         self._x_last = x
+        return feat
+
+    # -- fp32-accurate forward (evaluation only) --
+    def record_forward_exact(self, plan: Plan, ws: Workspace, img: torch.Tensor, B: int):
+        """Same network with every Linear evaluated as three bf16 GEMMs on hi / lo operand pairs
+        and everything else in f32.  Returns the f32 token-major output of the last LayerNorm."""
+        E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
+        H, W = self.img_hw
+        st = self.store
+
+        def wl(n):
+            return st.lview(self.pre + n)
+        ch, cl = ws.bf16('x_pe_hi', M, self.Kpe), ws.bf16('x_pe_lo', M, self.Kpe)
+        plan.patch_im2col_split(img, ch, cl, B, self.C, H, W, self.patch, self.stride, self.pad)
+        acc = ws.f32('x_acc', M, max(3 * E, Hd))
+        x, xm = ws.f32('x_xa', M, E), ws.f32('x_xb', M, E)
+        plan.gemm3(ch, cl, self.h('patch_embed.proj.weight'), wl('patch_embed.proj.weight'), acc, M, E, self.Kpe,
+                   ldx=self.Kpe, ldy=self.Kpe, ldo=E, bias=self.w('patch_embed.proj.bias'))
+        # + pos_embed[:, 1:] + pos_embed[:, :1] (one [T][E] table, broadcast over images)
+        pos_full = ws.f32('x_pos', M, E)
+        pc = self.pos_comb
+        plan.host(lambda: pos_full.view(B, T, E).copy_(pc.unsqueeze(0).expand(B, T, E)))
+        plan.finish_f32(acc, M, E, ldx=E, ldo=E, out=x, resid=pos_full, ldr=E)
+        y32 = ws.f32('x_ln', M, E)
+        yh, yl = ws.bf16('x_ln_hi', M, E), ws.bf16('x_ln_lo', M, E)
+        hh, hl = ws.bf16('x_h_hi', M, Hd), ws.bf16('x_h_lo', M, Hd)
+        ao = ws.f32('x_ao', M, E)
+        for i in range(self.depth):
+            b = f'blocks.{i}.'
+            plan.layernorm_fwd(x, self.w(b + 'norm1.weight'), self.w(b + 'norm1.bias'), None, y32, None, None, M, E)
+            plan.split_f32(y32, yh, yl, None, M * E)
+            plan.gemm3(yh, yl, self.h(b + 'attn.qkv.weight'), wl(b + 'attn.qkv.weight'), acc, M, 3 * E, E,
+                       ldx=E, ldy=E, ldo=3 * E,
+                       bias=self.w(b + 'attn.qkv.bias') if self.has(b + 'attn.qkv.bias') else None)
+            plan.attention_f32(acc, ao, B, self.heads, self.d, T, self.scale)
+            plan.split_f32(ao, yh, yl, None, M * E)
+            plan.gemm3(yh, yl, self.h(b + 'attn.proj.weight'), wl(b + 'attn.proj.weight'), acc, M, E, E,
+                       ldx=E, ldy=E, ldo=E, bias=self.w(b + 'attn.proj.bias'))
+            plan.finish_f32(acc, M, E, ldx=E, ldo=E, out=xm, resid=x, ldr=E)
+            plan.layernorm_fwd(xm, self.w(b + 'norm2.weight'), self.w(b + 'norm2.bias'), None, y32, None, None, M, E)
+            plan.split_f32(y32, yh, yl, None, M * E)
+            plan.gemm3(yh, yl, self.h(b + 'mlp.fc1.weight'), wl(b + 'mlp.fc1.weight'), acc, M, Hd, E,
+                       ldx=E, ldy=E, ldo=Hd, bias=self.w(b + 'mlp.fc1.bias'))
+            plan.finish_f32(acc, M, Hd, ldx=Hd, ldo=Hd, hi=hh, lo=hl, act=1)
+            plan.gemm3(hh, hl, self.h(b + 'mlp.fc2.weight'), wl(b + 'mlp.fc2.weight'), acc, M, E, Hd,
+                       ldx=Hd, ldy=Hd, ldo=E, bias=self.w(b + 'mlp.fc2.bias'))
+            plan.finish_f32(acc, M, E, ldx=E, ldo=E, out=x, resid=xm, ldr=E)
+        feat = ws.f32('x_feat', M, E)
+        if self.cfg.get('last_norm', True):
+            plan.layernorm_fwd(x, self.w('last_norm.weight'), self.w('last_norm.bias'), None, feat, None, None, M, E)
+        else:
+            plan.strided_cast(x, feat, (1, 1, 1, M * E), (0, 0, 0, 1))
         return feat
 
     # -- backward (training workspaces of record_forward(training=True) required) --

@@ -965,12 +965,16 @@ class TopDown(nn.Module):
             losses.update(self.keypoint_head.get_accuracy(output, target, target_weight))
         return losses
 
+    def _exact(self):
+        """test_cfg['fp32_exact'] (extension): evaluate at the reference's fp32 accuracy instead of bf16."""
+        return bool((self.test_cfg or {}).get('fp32_exact', False))
+
     def _infer_heatmap(self, img, flip_pairs=None):
         """backbone + head.inference_model (-> host array); one fused plan when available."""
         if self._engine is not None and not self.training:
             _need_hip(img, 'TopDown.forward_test')
             self._refresh()
-            heat = self._engine.infer(img.float(), copy_out=False).cpu().numpy()
+            heat = self._engine.infer(img.float(), copy_out=False, exact=self._exact()).cpu().numpy()
             if flip_pairs is not None:
                 heat = flip_back(heat, flip_pairs, target_type=self.keypoint_head.target_type)
                 if self.keypoint_head.test_cfg.get('shift_heatmap', False):
@@ -1004,7 +1008,7 @@ class TopDown(nn.Module):
         """top_down.py:202-218."""
         if self._engine is not None and not self.training and not torch.is_grad_enabled():
             self._refresh()
-            return self._engine.infer(img.float())
+            return self._engine.infer(img.float(), exact=self._exact())
         output = self.backbone(img)
         if self.with_neck:
             output = self.neck(output)

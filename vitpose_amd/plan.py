@@ -273,6 +273,35 @@ class Plan:
         _chk(img, torch.float32, 'img')
         self._add('vp_patch_im2col', _p(img), _p(col), B, C, H, W, patch, stride, pad, keep=(img, col))
 
+    # -- fp32-accurate path (hi / lo bf16 operand pairs) --
+    def gemm3(self, xh, xl, wh, wl, acc, M, N, K, *, ldx, ldy, ldo, bias=None):
+        """acc (f32) = x w^T + bias with x = xh + xl, w = wh + wl: three MFMA GEMMs chained through
+        the f32 accumulate epilogue (the lo * lo term, ~2^-16 relative, is dropped)."""
+        self.gemm(xh, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_F32, bias=bias)
+        self.gemm(xh, wl, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc)
+        self.gemm(xl, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc)
+
+    def finish_f32(self, x, M, N, *, ldx, ldo, out=None, hi=None, lo=None, colscale=None, colshift=None, act=0,
+                   resid=None, ldr=0, rowscale=None, rows_per_scale=0, row_map=None):
+        _chk(x, torch.float32, 'x')
+        rm = (ctypes.c_int * 4)(*row_map) if row_map is not None else None
+        self._add('vp_finish_f32', _p(x), ldx, _p(colscale), _p(colshift), act, _p(resid), ldr, _p(rowscale),
+                  rows_per_scale, _p(out), _p(hi), _p(lo), ldo, M, N, ctypes.byref(rm) if rm is not None else None,
+                  keep=(x, colscale, colshift, resid, rowscale, out, hi, lo, rm))
+
+    def split_f32(self, x, hi, lo, lo_f32, n):
+        _chk(x, torch.float32, 'x')
+        self._add('vp_split_f32', _p(x), _p(hi), _p(lo), _p(lo_f32), n, keep=(x, hi, lo, lo_f32))
+
+    def attention_f32(self, qkv, out, B, H, d, tokens, scale):
+        _chk(qkv, torch.float32, 'qkv')
+        self._add('vp_attention_f32', _p(qkv), _p(out), B, H, d, tokens, scale, keep=(qkv, out))
+
+    def patch_im2col_split(self, img, col_hi, col_lo, B, C, H, W, patch, stride, pad):
+        _chk(img, torch.float32, 'img')
+        self._add('vp_patch_im2col_split', _p(img), _p(col_hi), _p(col_lo), B, C, H, W, patch, stride, pad,
+                  keep=(img, col_hi, col_lo))
+
     def strided_cast(self, src, dst, dims, strides):
         dt = {torch.float32: _lib.VP_F32, torch.bfloat16: _lib.VP_BF16}
         d = (ctypes.c_int * 4)(*dims)

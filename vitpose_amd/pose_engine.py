@@ -41,6 +41,7 @@ class PoseEngine:
         self.head.record_weight_prep(self.prep)
         self.prep_derived = Plan()  # after an optimizer step the bf16 mirror is already fresh
         self.head.record_weight_prep(self.prep_derived)
+        self.prep_exact = None      # lo halves of the weights, built on the first exact evaluation
         self.optimizer = None
         self.comm = None
         # weight-gradient GEMMs on a second HIP stream (VITPOSE_SIDE_STREAM=0 keeps one stream)
@@ -90,11 +91,36 @@ class PoseEngine:
             self.plans[key] = (plan, img, heat)
         return self.plans[key]
 
+    def _exact_plan(self, B):
+        """fp32-accurate evaluation (three bf16 MFMA GEMMs per Linear / conv on hi + lo operand pairs,
+        everything else in f32): parity with the reference's fp32 forward at ~1e-5 relative, ~4x the cost."""
+        key = ('exact', B)
+        if key not in self.plans:
+            if self.prep_exact is None:
+                self.store.ensure_lo()
+                self.prep_exact = Plan()
+                self.prep_exact.split_f32(self.store.data, None, self.store.half_lo, self.store.data_lo,
+                                          self.store.numel)
+                self.head.record_weight_prep_exact(self.prep_exact)
+            ws = self.ws_infer
+            H, W = self.vit.img_hw
+            img = ws.f32('img', B, self.vit.C, H, W)
+            plan = Plan()
+            feat = self.vit.record_forward_exact(plan, ws, img, B)
+            oh, ow = self.head.out_grid
+            heat = ws.f32('heat', B, self.K, oh, ow)
+            self.head.record_forward_exact(plan, ws, feat, B, heat)
+            self.plans[key] = (plan, img, heat)
+        return self.plans[key]
+
     @torch.no_grad()
-    def infer(self, img: torch.Tensor, copy_out: bool = True) -> torch.Tensor:
-        """img [B,3,H,W] f32 on the device -> heatmaps [B,K,4Hp,4Wp] f32 (eval-mode BN)."""
+    def infer(self, img: torch.Tensor, copy_out: bool = True, exact: bool = False) -> torch.Tensor:
+        """img [B,3,H,W] f32 on the device -> heatmaps [B,K,4Hp,4Wp] f32 (eval-mode BN).
+        exact=True evaluates at fp32 accuracy (see _exact_plan)."""
         B = img.shape[0]
-        plan, img_in, heat = self._infer_plan(B)
+        plan, img_in, heat = self._exact_plan(B) if exact else self._infer_plan(B)
+        if exact:
+            self.prep_exact.run()
         if img.data_ptr() != img_in.data_ptr():
             img_in.copy_(img)
         plan.run()
