@@ -40,7 +40,7 @@ MODELS = {
               fwd_gflop=251.66),
 }
 EPI_NAMES = {0: 'VP_EPI_BF16', 1: 'VP_EPI_GELU', 2: 'VP_EPI_RESID_F32', 3: 'VP_EPI_DGELU', 4: 'VP_EPI_SPLITK_F32',
-             5: 'VP_EPI_F32', 6: 'VP_EPI_SCALE_RELU', 7: 'VP_EPI_DRELU'}
+             5: 'VP_EPI_F32', 6: 'VP_EPI_SCALE_RELU', 7: 'VP_EPI_DRELU', 100: 'grouped weight gradients, VP_EPI_F32'}
 
 
 def model_cfg(m):
@@ -229,6 +229,8 @@ def main():
         # one launcher (vp_gemm_bf16) serves three tile schedules (gemm_kernel 128x128, gemm192_kernel,
         # gemm256_kernel), chosen per shape by timing at plan-record time; the instantiation is <x_kmajor, y_kmajor, epilogue>
         kname = f'vp_gemm_bf16<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi}>'
+        if epi == 100:   # the grouped launcher runs gemm192_kernel / gemm256_kernel<true, true, VP_EPI_F32>
+            kname = 'vp_wgrad_grouped_bf16'
         out = {
             'metric': 'images/sec (256x192) ViTPose-B fwd+bwd at 1/2/4/8 GPUs; % bf16 MFMA roofline',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,

@@ -184,6 +184,24 @@ int vp_relu_bf16(const void* x, void* y, size_t n, vp_stream_t stream);
  * head fed by a foreign NCHW backbone, and of NCHW heat-map gradients (vit.py:330 is the inverse). */
 int vp_nchw_to_cl_bf16(const float* src, void* dst_bf16, int B, int C, int HW, int ld, vp_stream_t stream);
 
+/* Grouped weight gradients: several independent dW_i [M_i][N_i] = x_i^T y_i (x_i [K][M_i], y_i [K][N_i], bf16,
+ * reduction-major, f32 out, no K split) with one common reduction extent K (= tokens) in ONE launch, so that the
+ * tiles of all problems together fill the chip in whole rounds (the Linear weight gradients of several Blocks,
+ * vit.py:93-95,60-62 under autograd; none of them alone has enough tiles).
+ *   vp_wgrad_group_table: host-side; fills tiles_n / ntiles / tile0 of `problems` (host memory, <= 64 entries)
+ *     for the tile size (tile_mode 2: 256, 3: 192) and returns the grid size in *total_tiles.  The caller copies
+ *     the filled array to device memory.
+ *   vp_wgrad_grouped_bf16: the launch; `table_dev` is that device copy. */
+typedef struct vp_group_entry {
+    const void* x; const void* y; float* out;
+    int ldx, ldy, ldo, M, N;
+    int tiles_n, ntiles, tile0;   /* filled by vp_wgrad_group_table */
+    int reserved[2];
+} vp_group_entry;                 /* 64 bytes */
+int vp_wgrad_group_table(vp_group_entry* problems_host, int count, int tile_mode, int* total_tiles);
+int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K, int tile_mode,
+                          vp_stream_t stream);
+
 /* ----------------------------------------------------- fp32-accurate path ----------
  * Evaluation at the reference's fp32 accuracy (the 1e-3 max-abs heat-map tolerance on arbitrary
  * weights): every GEMM operand is a pair of bf16 arrays hi = bf16(x), lo = bf16(x - hi) and a

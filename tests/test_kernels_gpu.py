@@ -556,3 +556,20 @@ def test_patch_im2col_split(dev):
     run(lambda p: p.patch_im2col_split(img, ch, cl, B, 3, 256, 192, 16, 16, 2))
     ref = torch.nn.functional.unfold(img, 16, padding=2, stride=16).transpose(1, 2).reshape(B * 192, 768)
     assert torch.equal(ch, ref.bfloat16()) and torch.equal(cl, (ref - ch.float()).bfloat16())
+
+
+@pytest.mark.parametrize('mode', [2, 3])
+def test_wgrad_grouped_exact(dev, mode):
+    """Several weight-gradient problems of different shapes in one launch: every tile finds its own
+    problem (integer data: exact), including edge tiles and outputs with a wider leading dimension."""
+    K = 640
+    shapes = [(768, 384), (200, 136), (64, 1000), (384, 192), (8, 8), (520, 264)]
+    probs, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        x, y = ints((K, M), dev, seed=2 * i), ints((K, N), dev, seed=2 * i + 1)
+        out = torch.full((M, N), float('nan'), device=dev)
+        probs.append((x.bfloat16(), y.bfloat16(), out, M, N, M, N))
+        refs.append(x.t() @ y)
+    run(lambda p: p.wgrad_group(probs, K, tile_mode=mode))
+    for (x, y, out, *_), ref in zip(probs, refs):
+        assert torch.equal(out, ref)

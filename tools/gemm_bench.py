@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--tile-mode', type=int, default=0, help='0 autotuned, 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = 192x192 tiles')
+    ap.add_argument('--group-blocks', type=int, default=4)
     ap.add_argument('--wsplit', type=int, default=0, help='override the wgrad K split')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -47,6 +48,14 @@ def main():
         cases.append((f'wgrad_{name} M{N} N{K} K{M} split{sk}', 2.0 * M * N * K,
                       lambda p, dy=dy, x=x, dw=dw, slab=slab, N=N, K=K, sk=sk: p.wgrad(
                           dy, x, dw, N, K, M, ldx=N, ldy=K, split_k=sk, slab=slab, tile_mode=args.tile_mode)))
+    # grouped: the four Linear weight gradients of `--group-blocks` Blocks in one launch, no K split
+    probs = []
+    for blk in range(args.group_blocks):
+        for N, K in ((3 * E, E), (E, E), (4 * E, E), (E, 4 * E)):
+            probs.append((rb(M, N), rb(M, K), torch.empty(N, K, device=dev), N, K, N, K))
+    gflops = sum(2.0 * M * p[3] * p[4] for p in probs)
+    cases.append((f'wgrad_group {args.group_blocks} blocks ({len(probs)} problems)', gflops,
+                  lambda p: p.wgrad_group(probs, M, tile_mode=args.tile_mode if args.tile_mode in (2, 3) else 0)))
     for name, flops, build in cases:
         if args.only and args.only not in name:
             continue

@@ -37,8 +37,16 @@ class GemmArgs(Structure):
 
 P = c_void_p
 # name -> argtypes (the trailing stream argument included); every function returns int
+class GroupEntry(Structure):
+    _fields_ = [('x', c_void_p), ('y', c_void_p), ('out', c_void_p),
+                ('ldx', c_int), ('ldy', c_int), ('ldo', c_int), ('M', c_int), ('N', c_int),
+                ('tiles_n', c_int), ('ntiles', c_int), ('tile0', c_int), ('reserved', c_int * 2)]
+
+
 SIGNATURES = {
     'vp_gemm_bf16': [POINTER(GemmArgs), P],
+    'vp_wgrad_group_table': [POINTER(GroupEntry), c_int, c_int, POINTER(c_int)],
+    'vp_wgrad_grouped_bf16': [P, c_int, c_int, c_int, c_int, P],
     'vp_splitk_reduce': [P, c_int, c_long, c_size_t, P, c_int, P],
     'vp_layernorm_fwd': [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, c_size_t, P],

@@ -115,7 +115,7 @@ struct Epi {
 
 template <int EPI, int FM, int FN>
 __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
-                                             int M, int N) {
+                                             int M, int N, int slice = 0) {
     const int g = lane >> 4, li = lane & 15;
     int col[FN];
     bool cok[FN];
@@ -199,7 +199,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
             }
         } else {  // VP_EPI_F32, VP_EPI_SPLITK_F32 (slice blockIdx.y of the partial-sum slab)
             float* o = (float*)e.out + orow * e.ldo;
-            if constexpr (EPI == VP_EPI_SPLITK_F32) o += (size_t)blockIdx.y * e.split_stride;
+            if constexpr (EPI == VP_EPI_SPLITK_F32) o += (size_t)slice * e.split_stride;
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
                 const f32x4 v = acc[a][b] + bias[b];
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
             return;
         }
     }
-    run_epilogue<EPI, 4, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N);
+    run_epilogue<EPI, 4, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N, blockIdx.y);
 }
 
 // One workgroup per tail tile: sum the K-slice partials (same thread <-> fragment mapping as
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tail_fixup(int M, int N, int ti
             acc[a][b] = s;
         }
     }
-    run_epilogue<EPI, 4, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N);
+    run_epilogue<EPI, 4, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N, blockIdx.y);
 }
 
 // =====================================================================================
@@ -492,23 +492,50 @@ __device__ __forceinline__ void stage_half(const Operand& op, int r0, int k0, ch
     }
 }
 
+// Grouped launch (several independent weight-gradient problems with one reduction extent in one grid):
+// work id -> problem by a ballot over the table's first-tile column (<= 64 problems), then the problem's
+// operands replace the kernel arguments (wave-uniform: read through the scalar path).
+__device__ __forceinline__ void select_problem(const vp_group_entry* grp, int ngrp, int lane, int& work, Operand& X,
+                                               Operand& Y, int& M, int& N, int& tiles_n, int& ntiles, Epi& e) {
+    const int first = lane < ngrp ? grp[lane].tile0 : 0x7fffffff;
+    const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= work)) - 1);
+    const vp_group_entry g = grp[p];
+    X = Operand{(const bf16*)g.x, g.ldx, g.M};
+    Y = Operand{(const bf16*)g.y, g.ldy, g.N};
+    M = g.M;
+    N = g.N;
+    tiles_n = g.tiles_n;
+    ntiles = g.ntiles;
+    e.out = g.out;
+    e.ldo = g.ldo;
+    work -= g.tile0;
+}
+
 #define VP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 template <bool XKMAJ, bool YKMAJ, int EPI>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Operand Y, int M, int N, int K,
-                                                                int tiles_n, int ntiles, int ksplit_tiles, Epi e) {
+                                                                int tiles_n, int ntiles, int ksplit_tiles, Epi e,
+                                                                const vp_group_entry* gtab, int ngtab) {
     __shared__ __attribute__((aligned(16))) char lds[2][4][HALF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
 
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    // 1-D grid over (K slice, tile), slice-major: the contiguous chunk of work ids an XCD receives is a
+    // block of neighbouring tiles of ONE K slice, which walk the same operand panels in step (L2 reuse)
+    int work = xcd_remap(blockIdx.x, gridDim.x);
+    if constexpr (XKMAJ && YKMAJ && EPI == VP_EPI_F32) {
+        if (gtab) select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
+    }
+    const int slice = work / ntiles;
+    const int t = work - slice * ntiles;
     const int tiles_m = ntiles / tiles_n;
     const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
     const int gm = min(tiles_m - gid * 8, 8);
     const int i0 = (gid * 8 + tin % gm) * T2, j0 = (tin / gm) * T2;
     const int nk_all = K / BK;
-    const int kt0 = blockIdx.y * ksplit_tiles;
+    const int kt0 = slice * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
     const int nk = kt1 - kt0;
 
@@ -623,7 +650,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
             return;
         }
     }
-    run_epilogue<EPI, 8, 4>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N);
+    run_epilogue<EPI, 8, 4>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N, slice);
 }
 
 // =====================================================================================
@@ -680,19 +707,27 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s,
 
 template <bool XKMAJ, bool YKMAJ, int EPI>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Operand Y, int M, int N, int K,
-                                                                int tiles_n, int ntiles, int ksplit_tiles, Epi e) {
+                                                                int tiles_n, int ntiles, int ksplit_tiles, Epi e,
+                                                                const vp_group_entry* gtab, int ngtab) {
     __shared__ __attribute__((aligned(16))) char lds[3][STAGE3_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
 
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    // 1-D grid over (K slice, tile), slice-major: the contiguous chunk of work ids an XCD receives is a
+    // block of neighbouring tiles of ONE K slice, which walk the same operand panels in step (L2 reuse)
+    int work = xcd_remap(blockIdx.x, gridDim.x);
+    if constexpr (XKMAJ && YKMAJ && EPI == VP_EPI_F32) {
+        if (gtab) select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
+    }
+    const int slice = work / ntiles;
+    const int t = work - slice * ntiles;
     const int tiles_m = ntiles / tiles_n;
     const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
     const int gm = min(tiles_m - gid * 8, 8);
     const int i0 = (gid * 8 + tin % gm) * T3, j0 = (tin / gm) * T3;
     const int nk_all = K / BK;
-    const int kt0 = blockIdx.y * ksplit_tiles;
+    const int kt0 = slice * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
     const int nk = kt1 - kt0;
 
@@ -781,7 +816,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             return;
         }
     }
-    run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N);
+    run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice);
 }
 
 inline int num_cus() {
@@ -838,11 +873,11 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
     }
     if (a->tile_mode == 3) {
         const int tm3 = (a->M + T3 - 1) / T3, tn3 = (a->N + T3 - 1) / T3, nt3 = tm3 * tn3;
-        dim3 grid3(nt3, split);
+        dim3 grid3(nt3 * split);
 #define VP_GEMM3_CASE(EPI)                                                                             \
     case EPI:                                                                                          \
         hipLaunchKernelGGL((gemm192_kernel<XK, YK, EPI>), grid3, dim3(T2_THREADS), 0, st, X, Y, a->M, \
-                           a->N, a->K, tn3, nt3, ksplit_tiles, e);                                     \
+                           a->N, a->K, tn3, nt3, ksplit_tiles, e, nullptr, 0);                                     \
         break;
         switch (a->epilogue) {
             VP_GEMM3_CASE(VP_EPI_BF16)
@@ -865,11 +900,11 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
     if (a->tile_mode == 0) big = use_big_tiles(a->M, a->N, a->K, tm2 * tn2 * split, num_cus());
     if (big) {
         const int nt2 = tm2 * tn2;
-        dim3 grid2(nt2, split);
+        dim3 grid2(nt2 * split);
 #define VP_GEMM2_CASE(EPI)                                                                             \
     case EPI:                                                                                          \
         hipLaunchKernelGGL((gemm256_kernel<XK, YK, EPI>), grid2, dim3(T2_THREADS), 0, st, X, Y, a->M, \
-                           a->N, a->K, tn2, nt2, ksplit_tiles, e);                                     \
+                           a->N, a->K, tn2, nt2, ksplit_tiles, e, nullptr, 0);                                     \
         break;
         switch (a->epilogue) {
             VP_GEMM2_CASE(VP_EPI_BF16)
@@ -927,4 +962,40 @@ extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
     if (a->pos) VP_CHECK_ARG(a->pos_rows > 0);
     if (a->x_kmajor) return a->y_kmajor ? launch_layout<true, true>(a, stream) : launch_layout<true, false>(a, stream);
     return a->y_kmajor ? launch_layout<false, true>(a, stream) : launch_layout<false, false>(a, stream);
+}
+
+static int group_tile(int tile_mode) { return tile_mode == 2 ? T2 : T3; }
+
+extern "C" int vp_wgrad_group_table(vp_group_entry* problems, int count, int tile_mode, int* total_tiles) {
+    VP_CHECK_ARG(problems && total_tiles && count > 0 && count <= 64 && (tile_mode == 2 || tile_mode == 3));
+    const int T = group_tile(tile_mode);
+    int t0 = 0;
+    for (int i = 0; i < count; ++i) {
+        vp_group_entry& g = problems[i];
+        VP_CHECK_ARG(g.x && g.y && g.out && g.M >= 8 && g.N >= 8 && g.M % 8 == 0 && g.N % 8 == 0);
+        VP_CHECK_ARG(g.ldx % 8 == 0 && g.ldy % 8 == 0 && g.ldo % 4 == 0 && g.ldx >= g.M && g.ldy >= g.N && g.ldo >= g.N);
+        VP_CHECK_ARG(((uintptr_t)g.x & 15) == 0 && ((uintptr_t)g.y & 15) == 0 && ((uintptr_t)g.out & 15) == 0);
+        g.tiles_n = (g.N + T - 1) / T;
+        g.ntiles = ((g.M + T - 1) / T) * g.tiles_n;
+        g.tile0 = t0;
+        t0 += g.ntiles;
+    }
+    *total_tiles = t0;
+    return VP_OK;
+}
+
+extern "C" int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K,
+                                     int tile_mode, hipStream_t stream) {
+    VP_CHECK_ARG(table_dev && count > 0 && count <= 64 && total_tiles > 0 && K > 0 && K % BK == 0);
+    VP_CHECK_ARG(tile_mode == 2 || tile_mode == 3);
+    Operand none{nullptr, 0, 0};
+    Epi e{};
+    e.kind = VP_EPI_F32;
+    if (tile_mode == 2)
+        hipLaunchKernelGGL((gemm256_kernel<true, true, VP_EPI_F32>), dim3(total_tiles), dim3(T2_THREADS), 0, stream,
+                           none, none, 0, 0, K, 1, 1, K / BK, e, table_dev, count);
+    else
+        hipLaunchKernelGGL((gemm192_kernel<true, true, VP_EPI_F32>), dim3(total_tiles), dim3(T2_THREADS), 0, stream,
+                           none, none, 0, 0, K, 1, 1, K / BK, e, table_dev, count);
+    VP_LAUNCH_RET();
 }

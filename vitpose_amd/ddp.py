@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 class GradBuckets:
     def __init__(self, store, backbone_prefix='backbone.', head_prefix='keypoint_head.', depth=12,
-                 blocks_per_bucket=3, process_group=None):
+                 blocks_per_bucket=4, process_group=None):
         self.store = store
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -43,12 +43,12 @@ class GradBuckets:
         self.triggers = {}
         hi = end
         i = depth - 1
-        while i > 0:
-            lo_blk = max(1, i - blocks_per_bucket + 1)
+        while i >= blocks_per_bucket:
+            lo_blk = i - blocks_per_bucket + 1
             self.triggers[lo_blk] = (self.bounds[lo_blk], hi)
             hi = self.bounds[lo_blk]
             i = lo_blk - 1
-        self.tail = (0, hi)  # block 0 + patch/pos embedding: sent when backward ends
+        self.tail = (0, hi)  # the first (up to blocks_per_bucket) blocks + patch/pos embedding: when backward ends
 
     # -- called from plan.host closures (i.e. in stream order of the compute stream) --
     def _launch(self, lo, hi):

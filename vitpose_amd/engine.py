@@ -11,6 +11,7 @@ Data layout in HBM (one process per GPU):
     the attention probabilities.
 """
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -110,6 +111,8 @@ class Workspace:
 
 
 SPLITK_TARGET_BLOCKS = 512  # ~2 workgroups per CU
+# Blocks whose weight gradients share one grouped launch (0: one split-K launch per weight instead)
+WGRAD_GROUP_BLOCKS = int(os.environ.get('VITPOSE_WGRAD_GROUP', '4'))
 
 
 def _split_k(M, N, K, target_blocks=None):
@@ -327,10 +330,12 @@ class VitRunner:
 
     # -- backward (training workspaces of record_forward(training=True) required) --
     def record_backward(self, plan: Plan, ws: Workspace, dfeat: torch.Tensor, B: int,
-                        dp: Optional[torch.Tensor] = None, after_block=None):
-        """dfeat = bf16 [B*T][E] gradient wrt the final feature.  Accumulates into store.grad."""
+                        dp: Optional[torch.Tensor] = None, after_block=None, sync_blocks=(),
+                        group_blocks: Optional[int] = None):
+        """dfeat = bf16 [B*T][E] gradient wrt the final feature.  Writes the gradients into store.grad
+        (zeroed by the caller).  `after_block(plan, i)` is called once block i is finished and every
+        gradient of blocks >= i is final for each i in `sync_blocks` (the all-reduce trigger points)."""
         E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
-        slab = ws.f32('splitk_slab', _slab_elems(max(E * Hd, 3 * E * E, E * self.Kpe), M))
 
         def dp_scale(i, j):
             if dp is not None and i >= 0 and self.dp_rates[i] > 0:
@@ -348,6 +353,27 @@ class VitRunner:
         # before overwriting; fork() makes the side stream wait for the producer.
         def dxb_buf(tag):
             return ws.bf16(f'dxb.{tag}', M, E)
+        # None of a Block's four weight gradients has enough output tiles to fill 256 CUs without cutting
+        # the token reduction into slices (f32 partial slabs + a reduce pass).  They are not needed before
+        # the optimizer (or the block's all-reduce bucket), so they are deferred and issued as ONE grouped
+        # launch per `group_blocks` Blocks: 4 Blocks of ViTPose-B are 768 tiles of 192 x 192 = 3 whole
+        # rounds of the chip, no slices, no slabs.
+        G = group_blocks if group_blocks is not None else WGRAD_GROUP_BLOCKS
+        slab = ws.f32('splitk_slab', _slab_elems(max(E * Hd, 3 * E * E, E * self.Kpe), M)) if G <= 0 else None
+        pending = []
+
+        def defer(x, y, name, Mw, Nw):
+            if G <= 0:
+                plan.wgrad(x, y, self.g(name), Mw, Nw, M, ldx=Mw, ldy=Nw, split_k=_split_k(Mw, Nw, M), slab=slab)
+            else:
+                pending.append((x, y, self.g(name), Mw, Nw, Mw, Nw))
+
+        def flush():
+            if pending:
+                plan.fork()
+                with plan.on_side():
+                    plan.wgrad_group(list(pending), M)
+                pending.clear()
         last = self.depth - 1
         x_last = ws.bufs[f'x_in.{self.depth}']
         dxb = dxb_buf(f'{last}.mlp')
@@ -371,11 +397,9 @@ class VitRunner:
                       epilogue=_lib.VP_EPI_DGELU, aux=g['u' + s], ldaux=Hd)
             plan.fork()
             with plan.on_side():
-                # dW2 [E][Hd] += dxb^T h ; dW1 [Hd][E] += du^T xn2 ; db1 = colsum(du)
-                plan.wgrad(dxb, g['h' + s], self.g(b + 'mlp.fc2.weight'), E, Hd, M, ldx=E, ldy=Hd,
-                           split_k=_split_k(E, Hd, M), slab=slab)
-                plan.wgrad(du, g['xn2' + s], self.g(b + 'mlp.fc1.weight'), Hd, E, M, ldx=Hd, ldy=E,
-                           split_k=_split_k(Hd, E, M), slab=slab)
+                # dW2 [E][Hd] = dxb^T h ; dW1 [Hd][E] = du^T xn2 ; db1 = colsum(du)
+                defer(dxb, g['h' + s], b + 'mlp.fc2.weight', E, Hd)
+                defer(du, g['xn2' + s], b + 'mlp.fc1.weight', Hd, E)
                 plan.colsum(du, self.g(b + 'mlp.fc1.bias'), M, Hd, Hd)
             # dxn2 = du W1
             plan.gemm(du, self.h(b + 'mlp.fc1.weight'), dxn, M, E, Hd, ldx=Hd, ldy=E, ldo=E, y_kmajor=True)
@@ -391,10 +415,8 @@ class VitRunner:
                                self.scale)
             plan.fork()
             with plan.on_side():
-                plan.wgrad(dxb, g['ao' + s], self.g(b + 'attn.proj.weight'), E, E, M, ldx=E, ldy=E,
-                           split_k=_split_k(E, E, M), slab=slab)
-                plan.wgrad(dqkv, g['xn1' + s], self.g(b + 'attn.qkv.weight'), 3 * E, E, M, ldx=3 * E, ldy=E,
-                           split_k=_split_k(3 * E, E, M), slab=slab)
+                defer(dxb, g['ao' + s], b + 'attn.proj.weight', E, E)
+                defer(dqkv, g['xn1' + s], b + 'attn.qkv.weight', 3 * E, E)
                 if self.has(b + 'attn.qkv.bias'):
                     plan.colsum(dqkv, self.g(b + 'attn.qkv.bias'), M, 3 * E, 3 * E)
             plan.gemm(dqkv, self.h(b + 'attn.qkv.weight'), dxn, M, E, 3 * E, ldx=3 * E, ldy=E, ldo=E, y_kmajor=True)
@@ -406,15 +428,18 @@ class VitRunner:
                                dx, other, dxb, dp_scale(i - 1, 1), T, self.g(b + 'norm1.weight'),
                                self.g(b + 'norm1.bias'), nxt_bias, M, E, workspace=lnws)
             dx, other = other, dx
-            if after_block is not None and i > 0:
+            sync = after_block is not None and i > 0 and i in sync_blocks
+            if i > 0 and (sync or (G > 0 and i % G == 0)):
+                flush()
+            if sync:
                 # every gradient of blocks >= i is final here except fc2.bias of block i-1
                 plan.join()
                 after_block(plan, i)
         # ---- patch embedding + position embedding
         plan.fork()
         with plan.on_side():
-            plan.wgrad(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
-                       split_k=_split_k(E, self.Kpe, M), slab=slab)
+            defer(dxb, ws.bufs['pe_col'], 'patch_embed.proj.weight', E, self.Kpe)
+        flush()
         plan.batch_sum(dx, self.dpos, B, T * E)
         gp = self.g('pos_embed')[0]
 

@@ -1070,7 +1070,7 @@ class TopDown(nn.Module):
                                      max_grad_norm=(grad_clip or {}).get('max_norm', 0.0), frozen=frozen)
         return _FlatOptimizer(self)
 
-    def enable_ddp(self, process_group=None, blocks_per_bucket=3):
+    def enable_ddp(self, process_group=None, blocks_per_bucket=4):
         """Batch-sharded data parallelism over RCCL: gradient buckets are all-reduced from inside the
         backward plan (replaces MMDistributedDataParallel, mmpose/apis/train.py:116-133)."""
         if self._engine is None:

@@ -248,6 +248,43 @@ class Plan:
                   epilogue=_lib.VP_EPI_SPLITK_F32, split_k=split_k, split_stride=M * N, tile_mode=tile_mode)
         self._add('vp_splitk_reduce', _p(slab), split_k, M * N, M * N, _p(out), int(accumulate), keep=(slab, out))
 
+    def wgrad_group(self, problems, K, tile_mode=0):
+        """One launch for several independent weight gradients out_i [M_i][N_i] = x_i^T y_i over a common
+        reduction extent K.  problems: list of (x [K][M] bf16, y [K][N] bf16, out f32, M, N, ldx, ldy)."""
+        from ._lib import GroupEntry
+        n = len(problems)
+        dev = problems[0][2].device
+
+        def table(mode):
+            arr = (GroupEntry * n)()
+            for g, (x, y, out, M, N, ldx, ldy) in zip(arr, problems):
+                _chk(x, torch.bfloat16, 'x'), _chk(y, torch.bfloat16, 'y'), _chk(out, torch.float32, 'out')
+                g.x, g.y, g.out, g.ldx, g.ldy, g.ldo, g.M, g.N = x.data_ptr(), y.data_ptr(), out.data_ptr(), ldx, ldy, N, M, N
+            total = ctypes.c_int(0)
+            rc = self.L.vp_wgrad_group_table(arr, n, mode, ctypes.byref(total))
+            if rc != 0:
+                raise KernelError(f'vp_wgrad_group_table -> {rc}')
+            blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            return blob, total.value
+        if tile_mode == 0:
+            key = ('wgrad_group', tuple((p[3], p[4]) for p in problems), K, str(dev))
+            if AUTOTUNE and key not in _TUNE_CACHE:
+                best = None
+                s_ = c_void_p(torch.cuda.current_stream().cuda_stream)
+                for mode in (2, 3):
+                    blob, total = table(mode)
+                    t = _time_launch(lambda: self.L.vp_wgrad_grouped_bf16(_p(blob), n, total, K, mode, s_))
+                    if best is None or t < best[0]:
+                        best = (t, mode)
+                _TUNE_CACHE[key] = best[1]
+            tile_mode = _TUNE_CACHE.get(key, 3)
+        blob, total = table(tile_mode)
+        keep = [blob] + [t for p in problems for t in p[:3]]
+        # timing tag in the (x_kmajor, y_kmajor, epilogue, M, N, K) form of gemm(): epilogue 100 = grouped,
+        # M * N = summed output elements
+        self.tags[len(self.calls)] = (1, 1, 100, sum(p[3] * p[4] for p in problems), 1, K)
+        self._add('vp_wgrad_grouped_bf16', _p(blob), n, total, K, tile_mode, keep=tuple(keep))
+
     def layernorm_fwd(self, x, gamma, beta, y_bf16, y_f32, mean, rstd, M, E, eps=1e-6):
         _chk(x, torch.float32, 'x')
         self._add('vp_layernorm_fwd', _p(x), _p(gamma), _p(beta), _p(y_bf16), _p(y_f32), _p(mean), _p(rstd),

@@ -44,10 +44,12 @@ class PoseEngine:
         self.prep_exact = None      # lo halves of the weights, built on the first exact evaluation
         self.optimizer = None
         self.comm = None
-        # weight-gradient GEMMs on a second HIP stream (VITPOSE_SIDE_STREAM=0 keeps one stream)
-        self.side_stream_wgrad = os.environ.get('VITPOSE_SIDE_STREAM', '1') != '0'
+        # VITPOSE_SIDE_STREAM=1 puts the weight-gradient launches on a second HIP stream.  Off by default:
+        # once the weight gradients of several Blocks share one grouped launch that fills the chip, running
+        # it beside the dependent chain only makes both wait for each other's workgroups (measured 0.6 % slower).
+        self.side_stream_wgrad = os.environ.get('VITPOSE_SIDE_STREAM', '0') == '1'
 
-    def enable_ddp(self, process_group=None, blocks_per_bucket=3):
+    def enable_ddp(self, process_group=None, blocks_per_bucket=4):
         """Batch-sharded data parallelism: all-reduce the flat gradient buffer in buckets launched
         from inside the backward plan (call before the first training step)."""
         from .ddp import GradBuckets
@@ -150,7 +152,8 @@ class PoseEngine:
             dfeat = self.head.record_backward(plan, ws, feat, dheat, B)
             comm = self.comm
             self.vit.record_backward(plan, ws, dfeat, B, dp=io['dp'],
-                                     after_block=comm.after_block if comm is not None else None)
+                                     after_block=comm.after_block if comm is not None else None,
+                                     sync_blocks=tuple(comm.triggers) if comm is not None else ())
             if comm is not None:
                 comm.finish(plan)
             self.plans[key] = (plan, io)
