@@ -202,6 +202,25 @@ int vp_wgrad_group_table(vp_group_entry* problems_host, int count, int tile_mode
 int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K, int tile_mode,
                           vp_stream_t stream);
 
+/* ------------------------------------------------------------- Test-time decode ----
+ * vp_flip_back_avg: out = (heat + flip_back(heat_flipped)) * 0.5 — flip_back (core/post_processing/
+ *   post_transforms.py:54-95: swap the left/right joint channels, mirror the width axis; `perm[k]` = the
+ *   channel that lands in k) with the optional one-pixel shift (topdown_heatmap_simple_head.py:259-261) and
+ *   the flip-test average of TopDown.forward_test (top_down.py:181-189).
+ * vp_decode_heatmaps: keypoints_from_heatmaps (core/evaluation/top_down_eval.py:474-622) up to the map back
+ *   to image coordinates: per map the first arg-max (_get_max_preds, :63-95; (-1, -1) when the maximum is
+ *   <= 0), then mode 0: nothing; 1: the +-0.25 shift of post_process='default' (:598-610); 2: DARK-UDP
+ *   (post_dark_udp, :335-396): cv2.GaussianBlur(ksize = ntaps, sigma 0; separable f32, BORDER_REFLECT_101) at
+ *   the 7 stencil points only, clip to [0.001, 50], log, Newton step with the f64 2 x 2 inverse.  `taps_host`
+ *   (HOST pointer, copied into the kernel arguments) = the 1-D blur kernel.  preds [maps][2] (x, y) in
+ *   heat-map pixels, maxvals [maps].  An invalid joint reads the stencil clamped at the map corner (the
+ *   reference's flat index wraps into a neighbouring map there). */
+#define VP_DECODE_MAX_KERNEL 31
+int vp_flip_back_avg(const float* heat, const float* heat_flipped, const int* perm, int shift, float* out,
+                     int N, int K, int H, int W, vp_stream_t stream);
+int vp_decode_heatmaps(const float* heat, float* preds, float* maxvals, int maps, int H, int W, int mode,
+                       const float* taps_host, int ntaps, vp_stream_t stream);
+
 /* ----------------------------------------------------- fp32-accurate path ----------
  * Evaluation at the reference's fp32 accuracy (the 1e-3 max-abs heat-map tolerance on arbitrary
  * weights): every GEMM operand is a pair of bf16 arrays hi = bf16(x), lo = bf16(x - hi) and a

@@ -244,9 +244,46 @@ def misc():
     print('misc.json written')
 
 
+def synth_heatmaps(N, K, H, W, seed):
+    """Smooth positive heat maps: one Gaussian bump per joint at a random sub-pixel centre + a noise floor
+    (bumps near the border included).  Same recipe as oracle/decode_oracle.py: synth_heatmaps."""
+    from oracle import decode_oracle as D
+    return D.synth_heatmaps(N, K, H, W, seed)
+
+
+def decode():
+    """keypoints_from_heatmaps / _taylor / post_dark_udp / transform_preds of the reference on seeded maps.
+    UDP-DARK is evaluated with modulate kernel 1 (cv2.GaussianBlur is then the identity; no cv2 here)."""
+    N, K, H, W = 4, 17, 64, 48
+    hm = synth_heatmaps(N, K, H, W, seed=70)
+    g = np.random.default_rng(71)
+    center = (g.random((N, 2)) * 200 + 50).astype(np.float32)
+    scale = (g.random((N, 2)) + 0.8).astype(np.float32)
+    out = {}
+    p, m = ref.keypoints_from_heatmaps(hm, center, scale)
+    out['default_preds'], out['default_maxvals'] = p, m
+    p, m = ref.keypoints_from_heatmaps(hm, center, scale, post_process=None)
+    out['none_preds'] = p
+    p, m = ref.keypoints_from_heatmaps(hm, center, scale, post_process='default', use_udp=True, kernel=1,
+                                       target_type='GaussianHeatmap')
+    out['udp_k1_preds'], out['udp_k1_maxvals'] = p, m
+    # post_dark_udp alone (heat-map pixel units), identity blur
+    coords, _ = ref._get_max_preds(hm)
+    out['dark_udp_k1_coords'] = ref.post_dark_udp(coords.copy(), hm.copy(), kernel=1)
+    # _taylor on the log maps at the arg-max
+    lg = np.log(np.maximum(hm, 1e-10))
+    out['taylor_coords'] = np.stack([np.stack([ref._taylor(lg[n][k], coords[n][k].copy()) for k in range(K)])
+                                     for n in range(N)])
+    out['transform_udp'] = ref.transform_preds(coords[0].copy(), center[0], scale[0], [W, H], use_udp=True)
+    out['transform_plain'] = ref.transform_preds(coords[0].copy(), center[0], scale[0], [W, H], use_udp=False)
+    out['center'], out['scale'] = center, scale
+    save('decode.npz', **out)
+
+
 if __name__ == '__main__':
     toy_vit()
     vitpose_s_eval()
     vitpose_s_train()
     block_widths()
     misc()
+    decode()

@@ -79,8 +79,18 @@ def _install_stubs():
         raise RuntimeError('checkpoint loading is not available in the stub loader')
     ck.load_checkpoint = load_checkpoint
 
-    # cv2: only touched inside Gaussian-blur decode branches we do not call
-    _mod('cv2')
+    # cv2 is not installed.  The decode fixtures call the reference's UDP branch with kernel size 1, for
+    # which cv2.GaussianBlur is the identity (its 1-tap kernel is [1.0]); any other size is refused, so no
+    # fixture ever contains a blur that did not come from OpenCV.
+    cv2 = _mod('cv2')
+
+    def GaussianBlur(src, ksize, sigma, dst=None):
+        if tuple(ksize) != (1, 1):
+            raise RuntimeError('cv2 is not available: only the identity blur (ksize 1) can be evaluated')
+        if dst is not None and dst is not src:
+            dst[...] = src
+        return src if dst is None else dst
+    cv2.GaussianBlur = GaussianBlur
 
     # mmcv.cnn layer builders and initialisers
     _mod('mmcv')
@@ -169,7 +179,7 @@ def load_reference():
         ViT=vit.ViT, TopdownHeatmapSimpleHead=head.TopdownHeatmapSimpleHead,
         JointsMSELoss=loss.JointsMSELoss, pose_pck_accuracy=ev.pose_pck_accuracy,
         flip_back=post.flip_back, resize=ops.resize, _get_max_preds=ev._get_max_preds,
-        keypoints_from_heatmaps=ev.keypoints_from_heatmaps,
+        keypoints_from_heatmaps=ev.keypoints_from_heatmaps, _taylor=ev._taylor, post_dark_udp=ev.post_dark_udp,
         transform_preds=post.transform_preds)
     return ns
 

@@ -443,27 +443,227 @@ def _get_max_preds(heatmaps):
     return preds, maxvals
 
 
+def gaussian_kernel1d(ksize: int) -> np.ndarray:
+    """The 1-D kernel cv2.GaussianBlur(src, (ksize, ksize), 0) builds (the reference blurs with sigma 0,
+    top_down_eval.py:366,435,575): OpenCV's fixed tables for ksize <= 7, otherwise
+    exp(-x^2 / (2 sigma^2)) with sigma = 0.3 * ((ksize - 1) / 2 - 1) + 0.8, normalised in double, stored as f32."""
+    assert ksize % 2 == 1 and ksize > 0
+    fixed = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+             7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+    if ksize in fixed:
+        return np.asarray(fixed[ksize], dtype=np.float32)
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-0.5 * x * x / (sigma * sigma))
+    return (k / k.sum()).astype(np.float32)
+
+
+def gaussian_blur2d(img: np.ndarray, ksize: int) -> np.ndarray:
+    """cv2.GaussianBlur(img, (ksize, ksize), 0) on an f32 [H, W] array: separable, rows then columns, f32
+    intermediate, BORDER_REFLECT_101 (cv2's default border).  Returns a new array."""
+    k = gaussian_kernel1d(ksize)
+    r = ksize // 2
+    a = np.asarray(img, dtype=np.float32)
+    for axis in (1, 0):
+        pad = [(0, 0), (0, 0)]
+        pad[axis] = (r, r)
+        ap = np.pad(a, pad, mode='reflect')
+        out = np.zeros_like(a)
+        n = a.shape[axis]
+        for t in range(ksize):
+            sl = [slice(None), slice(None)]
+            sl[axis] = slice(t, t + n)
+            out += k[t] * ap[tuple(sl)]
+        a = out
+    return a
+
+
+def _gaussian_blur(heatmaps, kernel=11):
+    """top_down_eval.py:399-438: blur inside a zero border, then restore each map's maximum."""
+    assert kernel % 2 == 1
+    border = (kernel - 1) // 2
+    N, K, H, W = heatmaps.shape
+    for i in range(N):
+        for j in range(K):
+            origin_max = np.max(heatmaps[i, j])
+            dr = np.zeros((H + 2 * border, W + 2 * border), dtype=np.float32)
+            dr[border:-border, border:-border] = heatmaps[i, j].copy()
+            dr = gaussian_blur2d(dr, kernel)
+            heatmaps[i, j] = dr[border:-border, border:-border].copy()
+            heatmaps[i, j] *= origin_max / np.max(heatmaps[i, j])
+    return heatmaps
+
+
+def _taylor(heatmap, coord):
+    """top_down_eval.py:298-332 (DARK: second-order Taylor step on the log heat map)."""
+    H, W = heatmap.shape[:2]
+    px, py = int(coord[0]), int(coord[1])
+    if 1 < px < W - 2 and 1 < py < H - 2:
+        dx = 0.5 * (heatmap[py][px + 1] - heatmap[py][px - 1])
+        dy = 0.5 * (heatmap[py + 1][px] - heatmap[py - 1][px])
+        dxx = 0.25 * (heatmap[py][px + 2] - 2 * heatmap[py][px] + heatmap[py][px - 2])
+        dxy = 0.25 * (heatmap[py + 1][px + 1] - heatmap[py - 1][px + 1] - heatmap[py + 1][px - 1]
+                      + heatmap[py - 1][px - 1])
+        dyy = 0.25 * (heatmap[py + 2][px] - 2 * heatmap[py][px] + heatmap[py - 2][px])
+        if dxx * dyy - dxy ** 2 != 0:
+            hinv = np.linalg.inv(np.array([[dxx, dxy], [dxy, dyy]]))
+            coord += np.squeeze(np.array((-hinv @ np.array([[dx], [dy]])).T), axis=0)
+    return coord
+
+
+def post_dark_udp(coords, batch_heatmaps, kernel=3):
+    """top_down_eval.py:335-396: blur, clip to [0.001, 50], log, Newton step with the 3 x 3 stencil on
+    the edge-padded map.  Host version; `decode_udp_device` is the same arithmetic on the GPU."""
+    B, K, H, W = batch_heatmaps.shape
+    N = coords.shape[0]
+    assert B == 1 or B == N
+    for heatmaps in batch_heatmaps:
+        for heatmap in heatmaps:
+            heatmap[...] = gaussian_blur2d(heatmap, kernel)
+    np.clip(batch_heatmaps, 0.001, 50, batch_heatmaps)
+    np.log(batch_heatmaps, batch_heatmaps)
+    pad = np.pad(batch_heatmaps, ((0, 0), (0, 0), (1, 1), (1, 1)), mode='edge').flatten()
+    index = coords[..., 0] + 1 + (coords[..., 1] + 1) * (W + 2)
+    index += (W + 2) * (H + 2) * np.arange(0, B * K).reshape(-1, K)
+    index = index.astype(int).reshape(-1, 1)
+    i_, ix1, iy1 = pad[index], pad[index + 1], pad[index + W + 2]
+    ix1y1, ix1_y1_ = pad[index + W + 3], pad[index - W - 3]
+    ix1_, iy1_ = pad[index - 1], pad[index - 2 - W]
+    dx, dy = 0.5 * (ix1 - ix1_), 0.5 * (iy1 - iy1_)
+    derivative = np.concatenate([dx, dy], axis=1).reshape(N, K, 2, 1)
+    dxx, dyy = ix1 - 2 * i_ + ix1_, iy1 - 2 * i_ + iy1_
+    dxy = 0.5 * (ix1y1 - ix1 - iy1 + i_ + i_ - ix1_ - iy1_ + ix1_y1_)
+    hessian = np.concatenate([dxx, dxy, dxy, dyy], axis=1).reshape(N, K, 2, 2)
+    hessian = np.linalg.inv(hessian + np.finfo(np.float32).eps * np.eye(2))
+    coords -= np.einsum('ijmn,ijnk->ijmk', hessian, derivative).squeeze(-1)
+    return coords
+
+
 def keypoints_from_heatmaps(heatmaps, center, scale, unbiased=False, post_process='default', kernel=11,
                             valid_radius_factor=0.0546875, use_udp=False, target_type='GaussianHeatmap'):
-    """core/evaluation/top_down_eval.py:474-622 for post_process None / 'default' without UDP
-    (arg-max, quarter-pixel shift towards the higher neighbour, map back to the image).
-    The DARK / UDP / megvii refinements need cv2.GaussianBlur and are not covered."""
-    if unbiased or use_udp or post_process not in (None, 'default'):
-        raise NotImplementedError('decode covers post_process None / "default" without UDP / DARK')
+    """core/evaluation/top_down_eval.py:474-622, every branch: post_process None / 'default' / 'unbiased'
+    (DARK) / 'megvii', and UDP with 'GaussianHeatmap' (DARK-UDP) or 'CombinedTarget' targets.  The
+    reference blurs with cv2.GaussianBlur; `gaussian_blur2d` restates that filter."""
     heatmaps = heatmaps.copy()
+    if unbiased:
+        assert post_process not in [False, None, 'megvii']
+    if post_process in ['megvii', 'unbiased']:
+        assert kernel > 0
+    if use_udp:
+        assert not post_process == 'megvii'
+    if post_process is False:
+        warnings.warn('post_process=False is deprecated, please use post_process=None instead', DeprecationWarning)
+        post_process = None
+    elif post_process is True:
+        if unbiased is True:
+            warnings.warn("post_process=True, unbiased=True is deprecated, please use post_process='unbiased' instead",
+                          DeprecationWarning)
+            post_process = 'unbiased'
+        else:
+            warnings.warn("post_process=True, unbiased=False is deprecated, please use post_process='default' instead",
+                          DeprecationWarning)
+            post_process = 'default'
+    elif post_process == 'default':
+        if unbiased is True:
+            warnings.warn("unbiased=True is deprecated, please use post_process='unbiased' instead",
+                          DeprecationWarning)
+            post_process = 'unbiased'
+    if post_process == 'megvii':
+        heatmaps = _gaussian_blur(heatmaps, kernel=kernel)
     N, K, H, W = heatmaps.shape
-    preds, maxvals = _get_max_preds(heatmaps)
-    if post_process is not None:
-        for n in range(N):
-            for k in range(K):
-                hm = heatmaps[n][k]
-                px, py = int(preds[n][k][0]), int(preds[n][k][1])
-                if 1 < px < W - 1 and 1 < py < H - 1:
-                    diff = np.array([hm[py][px + 1] - hm[py][px - 1], hm[py + 1][px] - hm[py - 1][px]])
-                    preds[n][k] += np.sign(diff) * .25
+    if use_udp:
+        if target_type.lower() == 'GaussianHeatMap'.lower():
+            preds, maxvals = _get_max_preds(heatmaps)
+            preds = post_dark_udp(preds, heatmaps, kernel=kernel)
+        elif target_type.lower() == 'CombinedTarget'.lower():
+            for person_heatmaps in heatmaps:
+                for i, heatmap in enumerate(person_heatmaps):
+                    kt = 2 * kernel + 1 if i % 3 == 0 else kernel
+                    heatmap[...] = gaussian_blur2d(heatmap, kt)
+            valid_radius = valid_radius_factor * H
+            offset_x = heatmaps[:, 1::3, :].flatten() * valid_radius
+            offset_y = heatmaps[:, 2::3, :].flatten() * valid_radius
+            heatmaps = heatmaps[:, ::3, :]
+            preds, maxvals = _get_max_preds(heatmaps)
+            index = preds[..., 0] + preds[..., 1] * W
+            index += W * H * np.arange(0, N * K / 3)
+            index = index.astype(int).reshape(N, K // 3, 1)
+            preds += np.concatenate((offset_x[index], offset_y[index]), axis=2)
+        else:
+            raise ValueError("target_type should be either 'GaussianHeatmap' or 'CombinedTarget'")
+    else:
+        preds, maxvals = _get_max_preds(heatmaps)
+        if post_process == 'unbiased':
+            heatmaps = np.log(np.maximum(_gaussian_blur(heatmaps, kernel), 1e-10))
+            for n in range(N):
+                for k in range(K):
+                    preds[n][k] = _taylor(heatmaps[n][k], preds[n][k])
+        elif post_process is not None:
+            for n in range(N):
+                for k in range(K):
+                    hm = heatmaps[n][k]
+                    px, py = int(preds[n][k][0]), int(preds[n][k][1])
+                    if 1 < px < W - 1 and 1 < py < H - 1:
+                        diff = np.array([hm[py][px + 1] - hm[py][px - 1], hm[py + 1][px] - hm[py - 1][px]])
+                        preds[n][k] += np.sign(diff) * .25
+                        if post_process == 'megvii':
+                            preds[n][k] += 0.5
+    for i in range(N):
+        preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H], use_udp=use_udp)
+    if post_process == 'megvii':
+        maxvals = maxvals / 255.0 + 0.5
+    return preds, maxvals
+
+
+def _stream_ptr():
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_decode_mode(unbiased=False, post_process='default', use_udp=False, target_type='GaussianHeatmap'):
+    """Which vp_decode_heatmaps mode evaluates these keypoints_from_heatmaps settings (None: host only)."""
+    if unbiased or post_process in ('megvii', 'unbiased', True, False):
+        return None
+    if use_udp:
+        return 2 if target_type.lower() == 'gaussianheatmap' else None
+    return 1 if post_process == 'default' else (0 if post_process is None else None)
+
+
+def keypoints_from_heatmaps_device(heatmaps: torch.Tensor, center, scale, mode: int, kernel=11, use_udp=False):
+    """keypoints_from_heatmaps (top_down_eval.py:474-622) with the per-map work (arg-max, blur, log,
+    Newton step) in one HIP kernel: heat maps stay on the GPU, [N, K, 3] numbers come back."""
+    import ctypes
+    _need_hip(heatmaps, 'keypoints_from_heatmaps_device')
+    N, K, H, W = heatmaps.shape
+    hm = heatmaps.detach().contiguous().float()
+    out = torch.empty(N * K, 3, dtype=torch.float32, device=hm.device)
+    preds_d, max_d = out[:, :2].contiguous(), out[:, 2].contiguous()
+    taps = gaussian_kernel1d(kernel) if mode == 2 else np.zeros(1, np.float32)
+    taps_c = (ctypes.c_float * len(taps))(*taps.tolist())
+    rc = _lib.lib().vp_decode_heatmaps(hm.data_ptr(), preds_d.data_ptr(), max_d.data_ptr(), N * K, H, W, mode,
+                                       taps_c, len(taps), _stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f'vp_decode_heatmaps failed with status {rc}')
+    preds = preds_d.cpu().numpy().reshape(N, K, 2)
+    maxvals = max_d.cpu().numpy().reshape(N, K, 1)
     for i in range(N):
         preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H], use_udp=use_udp)
     return preds, maxvals
+
+
+def flip_back_avg_device(heat: torch.Tensor, heat_flipped: torch.Tensor, flip_pairs, shift: bool) -> torch.Tensor:
+    """(heat + flip_back(heat_flipped)) * 0.5 on the device (post_transforms.py:54-95, top_down.py:181-189)."""
+    N, K, H, W = heat.shape
+    perm = list(range(K))
+    for left, right in flip_pairs:
+        perm[left], perm[right] = right, left
+    perm_d = torch.tensor(perm, dtype=torch.int32, device=heat.device)
+    out = torch.empty_like(heat)
+    rc = _lib.lib().vp_flip_back_avg(heat.data_ptr(), heat_flipped.data_ptr(), perm_d.data_ptr(), int(bool(shift)),
+                                     out.data_ptr(), N, K, H, W, _stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f'vp_flip_back_avg failed with status {rc}')
+    return out
 
 
 def pose_pck_accuracy_device(output, target, mask, thr=0.05):
@@ -672,11 +872,21 @@ class TopdownHeatmapSimpleHead(_FlatBound):
                 score[i] = np.array(img_metas[i]['bbox_score']).reshape(-1)[0]
             if bbox_ids is not None:
                 bbox_ids.append(img_metas[i]['bbox_id'])
-        preds, maxvals = keypoints_from_heatmaps(
-            output, c, s, unbiased=self.test_cfg.get('unbiased_decoding', False),
-            post_process=self.test_cfg.get('post_process', 'default'), kernel=self.test_cfg.get('modulate_kernel', 11),
-            valid_radius_factor=self.test_cfg.get('valid_radius_factor', 0.0546875),
-            use_udp=self.test_cfg.get('use_udp', False), target_type=self.test_cfg.get('target_type', 'GaussianHeatmap'))
+        kw = dict(unbiased=self.test_cfg.get('unbiased_decoding', False),
+                  post_process=self.test_cfg.get('post_process', 'default'),
+                  use_udp=self.test_cfg.get('use_udp', False),
+                  target_type=self.test_cfg.get('target_type', 'GaussianHeatmap'))
+        kernel = self.test_cfg.get('modulate_kernel', 11)
+        mode = device_decode_mode(**kw) if torch.is_tensor(output) and output.is_cuda else None
+        if mode is not None:
+            # heat maps still on the GPU: decode there, only [N, K, 3] numbers cross to the host
+            preds, maxvals = keypoints_from_heatmaps_device(output, c, s, mode, kernel=kernel, use_udp=kw['use_udp'])
+        else:
+            if torch.is_tensor(output):
+                output = output.detach().cpu().numpy()
+            preds, maxvals = keypoints_from_heatmaps(
+                output, c, s, kernel=kernel,
+                valid_radius_factor=self.test_cfg.get('valid_radius_factor', 0.0546875), **kw)
         all_preds = np.zeros((batch_size, preds.shape[1], 3), dtype=np.float32)
         all_boxes = np.zeros((batch_size, 6), dtype=np.float32)
         all_preds[:, :, 0:2] = preds[:, :, 0:2]
@@ -987,14 +1197,31 @@ class TopDown(nn.Module):
 
     @torch.no_grad()
     def forward_test(self, img, img_metas, return_heatmap=False, **kwargs):
-        """top_down.py:163-200."""
+        """top_down.py:163-200.  With the fused HIP plan the heat maps stay on the GPU through the flip-test
+        average and the decode; they are copied to the host only when `return_heatmap` asks for them."""
         assert img.size(0) == len(img_metas)
         batch_size, _, img_height, img_width = img.shape
         if batch_size > 1:
             assert 'bbox_id' in img_metas[0]
         result = {}
+        head = self.keypoint_head if self.with_keypoint else None
+        flip = self.test_cfg.get('flip_test', True)
+        on_device = (self._engine is not None and not self.training and head is not None
+                     and head.target_type == 'GaussianHeatmap')
+        if on_device:
+            _need_hip(img, 'TopDown.forward_test')
+            self._refresh()
+            x = img.float()
+            heat = self._engine.infer(x, exact=self._exact())          # a copy: the plan's buffer is reused
+            if flip:
+                hf = self._engine.infer(x.flip(3), copy_out=False, exact=self._exact())
+                heat = flip_back_avg_device(heat, hf, img_metas[0]['flip_pairs'],
+                                            head.test_cfg.get('shift_heatmap', False))
+            result.update(head.decode(img_metas, heat, img_size=[img_width, img_height]))
+            result['output_heatmap'] = heat.cpu().numpy() if return_heatmap else None
+            return result
         output_heatmap = self._infer_heatmap(img)
-        if self.test_cfg.get('flip_test', True):
+        if flip:
             output_flipped_heatmap = self._infer_heatmap(img.flip(3), img_metas[0]['flip_pairs'])
             output_heatmap = (output_heatmap + output_flipped_heatmap) * 0.5
         if self.with_keypoint:
