@@ -81,7 +81,8 @@ typedef struct vp_gemm_args {
     float* tail_ws; size_t tail_ws_bytes;
     int tail_force;              /* 1: always split the tail round when tail_ws is given (default: heuristic) */
     int tile_mode;               /* 0: choose by shape; 1: 128x128 tiles (2 workgroups / CU); 2: 256x256 tiles (1 / CU);
-                                    3: 192x192 tiles (1 / CU, three LDS stages) */
+                                    3: 192x192 tiles (1 / CU, three LDS stages); 4: 192x128 tiles, 2 workgroups / CU
+                                    (k-contiguous x, no K split: VP_ERR_UNSUPPORTED otherwise) */
 } vp_gemm_args;
 
 int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);

@@ -42,6 +42,25 @@ def main():
         cases.append((f'dgrad_{name} M{M} N{K} K{N}', 2.0 * M * N * K,
                       lambda p, dy=dy, w=w, dx=dx, N=N, K=K: p.gemm(dy, w, dx, M, K, N, ldx=N, ldy=K, ldo=K,
                                                                     y_kmajor=True, tile_mode=args.tile_mode)))
+        if name == 'fc1':
+            u2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            bias = torch.zeros(N, device=dev)
+            cases.append((f'fwd_fc1+GELU M{M} N{N} K{K}', 2.0 * M * N * K,
+                          lambda p, x=x, w=w, out=out, u2=u2, bias=bias, N=N, K=K: p.gemm(
+                              x, w, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, out2=u2,
+                              epilogue=_lib.VP_EPI_GELU, tile_mode=args.tile_mode)))
+        if name == 'fc2':
+            aux = rb(M, K)
+            cases.append((f'dgrad_fc2+DGELU M{M} N{K} K{N}', 2.0 * M * N * K,
+                          lambda p, dy=dy, w=w, dx=dx, aux=aux, N=N, K=K: p.gemm(
+                              dy, w, dx, M, K, N, ldx=N, ldy=K, ldo=K, y_kmajor=True, epilogue=_lib.VP_EPI_DGELU,
+                              aux=aux, ldaux=K, tile_mode=args.tile_mode)))
+            r32, o32 = torch.zeros(M, N, device=dev), torch.empty(M, N, device=dev)
+            bias2 = torch.zeros(N, device=dev)
+            cases.append((f'fwd_fc2+RESID M{M} N{N} K{K}', 2.0 * M * N * K,
+                          lambda p, x=x, w=w, o32=o32, r32=r32, bias2=bias2, N=N, K=K: p.gemm(
+                              x, w, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias2, resid=r32,
+                              epilogue=_lib.VP_EPI_RESID_F32, tile_mode=args.tile_mode)))
         dw = torch.empty(N, K, device=dev)
         slab = torch.empty(_slab_elems(N * K, M), device=dev)
         sk = args.wsplit or _split_k(N, K, M)
@@ -61,6 +80,11 @@ def main():
             continue
         p = Plan()
         build(p)
+        try:
+            p.run()
+        except Exception as exc:  # noqa: BLE001  (a schedule that does not cover this layout)
+            print(f'{name:45s} unsupported ({exc})')
+            continue
         for _ in range(3):
             p.run()
         torch.cuda.synchronize()

@@ -43,10 +43,11 @@ struct Operand {
 // that the swizzled image keeps there (the swizzles are involutions).  No staging VGPRs and no
 // ds_write instructions: the register->LDS write path (~79 B/clk/CU) was the bottleneck of the
 // register-staged version, not the MFMAs.
-template <bool KMAJ>
+template <bool KMAJ, int ROWS = BM>
 __device__ __forceinline__ void stage_tile(const Operand& op, int r0, int k0, char* lds, int wave, int lane) {
+    static_assert(!KMAJ || ROWS == 128, "the k-major image is laid out for 128 columns");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
         const int base = (i * 4 + wave) * 64;  // first 16-byte slot written by this wave instruction
         const int L = base + lane;
         const bf16* src;
@@ -443,6 +444,82 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tail_fixup(int M, int N, int ti
     run_epilogue<EPI, 4, 4>(e, acc, i0 + wm * 64, j0 + wn * 64, lane, M, N, blockIdx.y);
 }
 
+#define VP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// =====================================================================================
+// 192 x 128 x 64 tile, 256 threads, TWO workgroups per CU
+// =====================================================================================
+// The one-workgroup-per-CU kernels below leave the MFMA pipes idle while their tile's epilogue drains
+// (all CUs store at once: an HBM-write burst of ~13 us per launch, a quarter of a K = 768 GEMM).  Here
+// two independent workgroups share a CU (2 x 80 KiB LDS, 2 waves / SIMD): one's epilogue and LDS reads
+// run under the other's MFMAs, and after the first round the workgroups of a CU are out of step for
+// good.  2 x 2 waves of 96 x 64 (6 x 4 MFMA tiles), two 40 KiB stages, one barrier per K step; X must
+// be k-contiguous (forward and dgrad products).  Its main loop is slower than the ping-pong kernels'
+// (the prefetch is only one K step deep), so it wins only where the epilogue is heavy: the exact-GELU
+// epilogue with its second output.  (A variant with 32-wide K stages in a ring of four prefetched deeper
+// but fetched half cache lines per row and was 10 % slower still.)
+constexpr int W_BM = 192, W_BN = 128;
+constexpr int W_XBYTES = W_BM * BK * 2, W_YBYTES = W_BN * BK * 2;   // 24 KiB + 16 KiB per stage
+
+template <bool YKMAJ, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand Y, int M, int N, int K, int tiles_n,
+                                                              int ntiles, Epi e) {
+    __shared__ __attribute__((aligned(16))) char lds[2][W_XBYTES + W_YBYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tiles_m = ntiles / tiles_n;
+    const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
+    const int gm = min(tiles_m - gid * 8, 8);
+    const int i0 = (gid * 8 + tin % gm) * W_BM, j0 = (tin / gm) * W_BN;
+    const int nk = K / BK;
+
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_tile<false, W_BM>(X, i0, 0, lds[0], wave, lane);
+    stage_tile<YKMAJ>(Y, j0, 0, lds[0] + W_XBYTES, wave, lane);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            stage_tile<false, W_BM>(X, i0, (kt + 1) * BK, lds[cur ^ 1], wave, lane);
+            stage_tile<YKMAJ>(Y, j0, (kt + 1) * BK, lds[cur ^ 1] + W_XBYTES, wave, lane);
+        }
+        const char* lx = lds[cur];
+        const char* ly = lds[cur] + W_XBYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 xf[6], yf[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) yf[b] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) xf[a] = read_frag<false>(lx, wm * 96 + a * 16, s, lane);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+    }
+    if constexpr (epi_is_bf16<EPI>()) {
+        if (((N | e.ldo) & 7) == 0) {   // the loop's last barrier: every wave is done with the operand tiles
+            run_epilogue_staged<EPI, 6, 4, 3>(e, acc, i0 + wm * 96, j0 + wn * 64, lane, M, N,
+                                              &lds[0][0] + wave * (48 * STG_PITCH));
+            return;
+        }
+    }
+    run_epilogue<EPI, 6, 4>(e, acc, i0 + wm * 96, j0 + wn * 64, lane, M, N);
+}
+
 // =====================================================================================
 // 256 x 256 x 64 tile, 512 threads, one workgroup per CU ("ping-pong" schedule)
 // =====================================================================================
@@ -511,7 +588,6 @@ __device__ __forceinline__ void select_problem(const vp_group_entry* grp, int ng
     work -= g.tile0;
 }
 
-#define VP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 template <bool XKMAJ, bool YKMAJ, int EPI>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Operand Y, int M, int N, int K,
@@ -870,6 +946,30 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
             tl = Tail{ntiles - ntail, ts, a->tail_ws};
             grid = dim3(tl.full + ntail * ts, 1);
         }
+    }
+    if (a->tile_mode == 4) {
+        if (XK || split > 1) return VP_ERR_UNSUPPORTED;   // forward / dgrad products only
+        const int tm4 = (a->M + W_BM - 1) / W_BM, tn4 = (a->N + W_BN - 1) / W_BN, nt4 = tm4 * tn4;
+        if constexpr (!XK) {
+#define VP_GEMM4_CASE(EPI)                                                                              \
+    case EPI:                                                                                           \
+        hipLaunchKernelGGL((gemm_w2_kernel<YK, EPI>), dim3(nt4), dim3(NTHREADS), 0, st, X, Y, a->M, \
+                           a->N, a->K, tn4, nt4, e);                                                    \
+        break;
+            switch (a->epilogue) {
+                VP_GEMM4_CASE(VP_EPI_BF16)
+                VP_GEMM4_CASE(VP_EPI_GELU)
+                VP_GEMM4_CASE(VP_EPI_RESID_F32)
+                VP_GEMM4_CASE(VP_EPI_DGELU)
+                VP_GEMM4_CASE(VP_EPI_F32)
+                VP_GEMM4_CASE(VP_EPI_SCALE_RELU)
+                VP_GEMM4_CASE(VP_EPI_DRELU)
+                default:
+                    return VP_ERR_ARG;
+            }
+#undef VP_GEMM4_CASE
+        }
+        VP_LAUNCH_RET();
     }
     if (a->tile_mode == 3) {
         const int tm3 = (a->M + T3 - 1) / T3, tn3 = (a->N + T3 - 1) / T3, nt3 = tm3 * tn3;

@@ -201,7 +201,7 @@ class Plan:
                 fn = self.L.vp_gemm_bf16
                 s_ = c_void_p(torch.cuda.current_stream().cuda_stream)
                 best = None
-                for mode in (1, 2, 3):
+                for mode in ((1, 2, 3) if x_kmajor else (1, 2, 3, 4)):
                     a.tile_mode = mode
                     t = _time_launch(lambda: fn(ctypes.byref(a), s_))
                     if best is None or t < best[0]:
