@@ -197,7 +197,7 @@ typedef struct vp_group_entry {
     const void* x; const void* y; float* out;
     int ldx, ldy, ldo, M, N;
     int tiles_n, ntiles, tile0;   /* filled by vp_wgrad_group_table */
-    int reserved[2];
+    float* rowsum;                /* optional [M]: rowsum[m] = sum_k x[k][m], the bias gradient of the same Linear */
 } vp_group_entry;                 /* 64 bytes */
 int vp_wgrad_group_table(vp_group_entry* problems_host, int count, int tile_mode, int* total_tiles);
 int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K, int tile_mode,

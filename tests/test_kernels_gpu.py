@@ -568,11 +568,14 @@ def test_wgrad_grouped_exact(dev, mode):
     for i, (M, N) in enumerate(shapes):
         x, y = ints((K, M), dev, seed=2 * i), ints((K, N), dev, seed=2 * i + 1)
         out = torch.full((M, N), float('nan'), device=dev)
-        probs.append((x.bfloat16(), y.bfloat16(), out, M, N, M, N))
+        rs = torch.full((M,), float('nan'), device=dev) if i % 2 == 0 else None   # every other problem: row sums too
+        probs.append((x.bfloat16(), y.bfloat16(), out, M, N, M, N, rs))
         refs.append(x.t() @ y)
     run(lambda p: p.wgrad_group(probs, K, tile_mode=mode))
-    for (x, y, out, *_), ref in zip(probs, refs):
+    for (x, y, out, *rest), ref in zip(probs, refs):
         assert torch.equal(out, ref)
+        if rest[-1] is not None:
+            assert torch.equal(rest[-1], x.float().sum(0))
 
 
 # ------------------------------------------------------------------ 192 x 128 tiles, 2 workgroups / CU

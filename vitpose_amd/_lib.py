@@ -40,7 +40,7 @@ P = c_void_p
 class GroupEntry(Structure):
     _fields_ = [('x', c_void_p), ('y', c_void_p), ('out', c_void_p),
                 ('ldx', c_int), ('ldy', c_int), ('ldo', c_int), ('M', c_int), ('N', c_int),
-                ('tiles_n', c_int), ('ntiles', c_int), ('tile0', c_int), ('reserved', c_int * 2)]
+                ('tiles_n', c_int), ('ntiles', c_int), ('tile0', c_int), ('rowsum', c_void_p)]
 
 
 SIGNATURES = {

@@ -18,6 +18,8 @@
 // k-major tiles with ds_read_b64_tr_b16 (hardware transpose, conflict-free).
 // The MFMA A operand is the Y tile and the B operand the X tile, so a lane ends
 // up with 4 consecutive columns of one C row: 8/16-byte epilogue accesses.
+#include <type_traits>
+
 #include "common.h"
 #include "vitpose_hip.h"
 
@@ -572,8 +574,8 @@ __device__ __forceinline__ void stage_half(const Operand& op, int r0, int k0, ch
 // Grouped launch (several independent weight-gradient problems with one reduction extent in one grid):
 // work id -> problem by a ballot over the table's first-tile column (<= 64 problems), then the problem's
 // operands replace the kernel arguments (wave-uniform: read through the scalar path).
-__device__ __forceinline__ void select_problem(const vp_group_entry* grp, int ngrp, int lane, int& work, Operand& X,
-                                               Operand& Y, int& M, int& N, int& tiles_n, int& ntiles, Epi& e) {
+__device__ __forceinline__ float* select_problem(const vp_group_entry* grp, int ngrp, int lane, int& work, Operand& X,
+                                                 Operand& Y, int& M, int& N, int& tiles_n, int& ntiles, Epi& e) {
     const int first = lane < ngrp ? grp[lane].tile0 : 0x7fffffff;
     const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= work)) - 1);
     const vp_group_entry g = grp[p];
@@ -586,6 +588,28 @@ __device__ __forceinline__ void select_problem(const vp_group_entry* grp, int ng
     e.out = g.out;
     e.ldo = g.ldo;
     work -= g.tile0;
+    return g.rowsum;
+}
+
+// Row sums of a grouped weight gradient, rowsum[m] = sum_k x[k][m] (the bias gradient that belongs to the
+// weight gradient x^T y): in the first column tile of a row panel each X fragment gets one more MFMA against
+// an all-ones operand (spread over the four waves that share the fragment), so the sum costs no pass over x.
+__device__ __forceinline__ bf16x8 ones8() {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)1.0f;
+    return o;
+}
+template <int FM>
+__device__ __forceinline__ void store_rowsum(float* rowsum, const f32x4 (&racc)[FM], int row0, int lane, int M,
+                                             int wc) {
+    if (lane < 16) {
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            const int row = row0 + a * 16 + lane;
+            if ((a & 3) == wc && row < M) rowsum[row] = racc[a][0];   // fragment a was summed by wave a % 4
+        }
+    }
 }
 
 
@@ -601,8 +625,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
     // 1-D grid over (K slice, tile), slice-major: the contiguous chunk of work ids an XCD receives is a
     // block of neighbouring tiles of ONE K slice, which walk the same operand panels in step (L2 reuse)
     int work = xcd_remap(blockIdx.x, gridDim.x);
+    float* rowsum = nullptr;
     if constexpr (XKMAJ && YKMAJ && EPI == VP_EPI_F32) {
-        if (gtab) select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
+        if (gtab) rowsum = select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
     }
     const int slice = work / ntiles;
     const int t = work - slice * ntiles;
@@ -620,8 +645,17 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool ROWSUM = XKMAJ && YKMAJ && EPI == VP_EPI_F32;
+    const bool do_rs = ROWSUM && rowsum != nullptr && j0 == 0;   // workgroup-uniform; fragment a goes to wave a % 4
+    f32x4 racc[ROWSUM ? 8 : 1];
+#pragma unroll
+    for (int a = 0; a < (ROWSUM ? 8 : 1); ++a) racc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = ones8();
 
-    if (nk > 0) {
+    // the K loop exists twice (generic lambda): with and without the row-sum MFMAs, so that the tiles
+    // without row sums (most of them) run the loop that has no trace of them
+    auto k_loop = [&](auto rs_tag) {
+        constexpr bool RS = decltype(rs_tag)::value;
         // slot 0/1 = X halves, 2/3 = Y halves; K tile u (relative) lives in stage u & 1
         auto stage = [&](int slot, int u) {
             const int k0 = (kt0 + (u < nk ? u : nk - 1)) * BK;
@@ -662,6 +696,16 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+            if constexpr (RS) {
+                {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+                            if (wc == a)
+                                racc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[a], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---- phase 1
@@ -697,6 +741,17 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
                     for (int b = 0; b < 2; ++b)
                         acc[4 + a][2 + b] =
                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][s], xf[a][s], acc[4 + a][2 + b], 0, 0, 0);
+            if constexpr (RS) {
+                {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+                            if (wc == a)
+                                racc[4 + a] =
+                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[4 + a], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---- phase 3
@@ -717,6 +772,14 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();   // match group 1's extra barrier
         VP_WAIT_VM(0);                                 // no LDS-DMA may outlive the workgroup
+    };
+    if (nk > 0) {
+        if constexpr (ROWSUM) {
+            if (do_rs) k_loop(std::true_type{});
+            else k_loop(std::false_type{});
+        } else {
+            k_loop(std::false_type{});
+        }
     }
     if constexpr (epi_is_bf16<EPI>()) {
         if (((N | e.ldo) & 7) == 0) {
@@ -725,6 +788,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
                                         &lds[0][0][0] + wave * STG_BYTES);
             return;
         }
+    }
+    if constexpr (ROWSUM) {
+        if (do_rs) store_rowsum<8>(rowsum, racc, i0 + grp * 128, lane, M, wc);
     }
     run_epilogue<EPI, 8, 4>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N, slice);
 }
@@ -793,8 +859,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     // 1-D grid over (K slice, tile), slice-major: the contiguous chunk of work ids an XCD receives is a
     // block of neighbouring tiles of ONE K slice, which walk the same operand panels in step (L2 reuse)
     int work = xcd_remap(blockIdx.x, gridDim.x);
+    float* rowsum = nullptr;
     if constexpr (XKMAJ && YKMAJ && EPI == VP_EPI_F32) {
-        if (gtab) select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
+        if (gtab) rowsum = select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
     }
     const int slice = work / ntiles;
     const int t = work - slice * ntiles;
@@ -812,8 +879,17 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool ROWSUM = XKMAJ && YKMAJ && EPI == VP_EPI_F32;
+    const bool do_rs = ROWSUM && rowsum != nullptr && j0 == 0;   // workgroup-uniform; fragment a goes to wave a % 4
+    f32x4 racc[ROWSUM ? 6 : 1];
+#pragma unroll
+    for (int a = 0; a < (ROWSUM ? 6 : 1); ++a) racc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = ones8();
 
-    if (nk > 0) {
+    // the K loop exists twice (generic lambda): with and without the row-sum MFMAs, so that the tiles
+    // without row sums (most of them) run the loop that has no trace of them
+    auto k_loop = [&](auto rs_tag) {
+        constexpr bool RS = decltype(rs_tag)::value;
         // unit 0-2 = X rows 0-63 / 64-127 / 128-191, 3-5 = Y columns likewise; K tile u lives in stage u % 3
         auto stage = [&](int unit, int u, int st) {
             const int k0 = (kt0 + (u < nk ? u : nk - 1)) * BK;
@@ -855,6 +931,16 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
 #pragma unroll
                     for (int b = 0; b < 3; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+            if constexpr (RS) {
+                {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            if (wc == a)
+                                racc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[a], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---- phase 1: rows 48-95
@@ -876,6 +962,17 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
                     for (int b = 0; b < 3; ++b)
                         acc[3 + a][b] =
                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[3 + a][b], 0, 0, 0);
+            if constexpr (RS) {
+                {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            if (wc == ((3 + a) & 3))
+                                racc[3 + a] =
+                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[3 + a], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             cur = cur == 2 ? 0 : cur + 1;
@@ -883,6 +980,14 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();   // match group 1's extra barrier
         VP_WAIT_VM(0);                                 // no LDS-DMA may outlive the workgroup
+    };
+    if (nk > 0) {
+        if constexpr (ROWSUM) {
+            if (do_rs) k_loop(std::true_type{});
+            else k_loop(std::false_type{});
+        } else {
+            k_loop(std::false_type{});
+        }
     }
     if constexpr (epi_is_bf16<EPI>()) {
         if (((N | e.ldo) & 7) == 0) {
@@ -891,6 +996,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
                                               &lds[0][0] + wave * (48 * 112));
             return;
         }
+    }
+    if constexpr (ROWSUM) {
+        if (do_rs) store_rowsum<6>(rowsum, racc, i0 + grp * 96, lane, M, wc);
     }
     run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice);
 }

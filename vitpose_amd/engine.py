@@ -362,11 +362,15 @@ class VitRunner:
         slab = ws.f32('splitk_slab', _slab_elems(max(E * Hd, 3 * E * E, E * self.Kpe), M)) if G <= 0 else None
         pending = []
 
-        def defer(x, y, name, Mw, Nw):
+        def defer(x, y, name, Mw, Nw, bias=None):
+            """Weight gradient x^T y (and, with `bias`, that Linear's bias gradient = column sums of x)."""
             if G <= 0:
                 plan.wgrad(x, y, self.g(name), Mw, Nw, M, ldx=Mw, ldy=Nw, split_k=_split_k(Mw, Nw, M), slab=slab)
+                if bias is not None:
+                    plan.colsum(x, self.g(bias), M, Mw, Mw)
             else:
-                pending.append((x, y, self.g(name), Mw, Nw, Mw, Nw))
+                # the grouped kernel sums the columns of x on the side (one extra MFMA per fragment)
+                pending.append((x, y, self.g(name), Mw, Nw, Mw, Nw, self.g(bias) if bias is not None else None))
 
         def flush():
             if pending:
@@ -399,8 +403,7 @@ class VitRunner:
             with plan.on_side():
                 # dW2 [E][Hd] = dxb^T h ; dW1 [Hd][E] = du^T xn2 ; db1 = colsum(du)
                 defer(dxb, g['h' + s], b + 'mlp.fc2.weight', E, Hd)
-                defer(du, g['xn2' + s], b + 'mlp.fc1.weight', Hd, E)
-                plan.colsum(du, self.g(b + 'mlp.fc1.bias'), M, Hd, Hd)
+                defer(du, g['xn2' + s], b + 'mlp.fc1.weight', Hd, E, bias=b + 'mlp.fc1.bias')
             # dxn2 = du W1
             plan.gemm(du, self.h(b + 'mlp.fc1.weight'), dxn, M, E, Hd, ldx=Hd, ldy=E, ldo=E, y_kmajor=True)
             # LN2 backward, residual add, scaled bf16 copy for the attention branch, proj bias grad
@@ -416,9 +419,8 @@ class VitRunner:
             plan.fork()
             with plan.on_side():
                 defer(dxb, g['ao' + s], b + 'attn.proj.weight', E, E)
-                defer(dqkv, g['xn1' + s], b + 'attn.qkv.weight', 3 * E, E)
-                if self.has(b + 'attn.qkv.bias'):
-                    plan.colsum(dqkv, self.g(b + 'attn.qkv.bias'), M, 3 * E, 3 * E)
+                defer(dqkv, g['xn1' + s], b + 'attn.qkv.weight', 3 * E, E,
+                      bias=b + 'attn.qkv.bias' if self.has(b + 'attn.qkv.bias') else None)
             plan.gemm(dqkv, self.h(b + 'attn.qkv.weight'), dxn, M, E, 3 * E, ldx=3 * E, ldy=E, ldo=E, y_kmajor=True)
             # LN1 backward: bf16 copy is scaled for the previous block's MLP branch (or unscaled for
             # the patch embedding), its column sum is that branch's fc2 bias (or the patch bias) grad

@@ -250,16 +250,21 @@ class Plan:
 
     def wgrad_group(self, problems, K, tile_mode=0):
         """One launch for several independent weight gradients out_i [M_i][N_i] = x_i^T y_i over a common
-        reduction extent K.  problems: list of (x [K][M] bf16, y [K][N] bf16, out f32, M, N, ldx, ldy)."""
+        reduction extent K.  problems: list of (x [K][M] bf16, y [K][N] bf16, out f32, M, N, ldx, ldy[, rowsum]);
+        rowsum (f32 [M], optional) receives sum_k x[k][m], the bias gradient of the same Linear."""
         from ._lib import GroupEntry
         n = len(problems)
         dev = problems[0][2].device
 
         def table(mode):
             arr = (GroupEntry * n)()
-            for g, (x, y, out, M, N, ldx, ldy) in zip(arr, problems):
+            for g, prob in zip(arr, problems):
+                x, y, out, M, N, ldx, ldy = prob[:7]
                 _chk(x, torch.bfloat16, 'x'), _chk(y, torch.bfloat16, 'y'), _chk(out, torch.float32, 'out')
                 g.x, g.y, g.out, g.ldx, g.ldy, g.ldo, g.M, g.N = x.data_ptr(), y.data_ptr(), out.data_ptr(), ldx, ldy, N, M, N
+                if len(prob) > 7 and prob[7] is not None:
+                    _chk(prob[7], torch.float32, 'rowsum')
+                    g.rowsum = prob[7].data_ptr()
             total = ctypes.c_int(0)
             rc = self.L.vp_wgrad_group_table(arr, n, mode, ctypes.byref(total))
             if rc != 0:
@@ -279,7 +284,7 @@ class Plan:
                 _TUNE_CACHE[key] = best[1]
             tile_mode = _TUNE_CACHE.get(key, 3)
         blob, total = table(tile_mode)
-        keep = [blob] + [t for p in problems for t in p[:3]]
+        keep = [blob] + [t for p in problems for t in p[:3]] + [p[7] for p in problems if len(p) > 7]
         # timing tag in the (x_kmajor, y_kmajor, epilogue, M, N, K) form of gemm(): epilogue 100 = grouped,
         # M * N = summed output elements
         self.tags[len(self.calls)] = (1, 1, 100, sum(p[3] * p[4] for p in problems), 1, K)
