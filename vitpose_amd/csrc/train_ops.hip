@@ -199,19 +199,33 @@ __global__ __launch_bounds__(256) void heatmap_loss_kernel(const float* __restri
         const int b = (int)(i / HW), hw = (int)(i % HW);
         const float* hp = heat + i * ldh;
         bf16* dp = dheat ? dheat + i * ldh : nullptr;
-        for (int k = 0; k < K; ++k) {
-            const float p = hp[k];
-            const size_t o = ((size_t)b * K + k) * HW + hw;
-            if (heat_nchw) heat_nchw[o] = p;
-            if (target) {
-                const float w = tw ? tw[b * K + k] : 1.f;
-                const float d = w * (p - target[o]);
-                part += d * d;
-                if (dp) dp[k] = (bf16)(2.f * w * d * coef);
+        // one pixel per thread, 8 channels at a time: two 16-byte loads, one 16-byte gradient store
+        // (per-channel NCHW accesses are contiguous across the wave's 64 pixels)
+        for (int k0 = 0; k0 < ldh; k0 += 8) {
+            bf16x8 g8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g8[j] = (bf16)0.f;
+            if (k0 < K) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(hp + k0);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(hp + k0 + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + j;
+                    if (k < K) {
+                        const float p = j < 4 ? lo[j] : hi[j - 4];
+                        const size_t o = ((size_t)b * K + k) * HW + hw;
+                        if (heat_nchw) heat_nchw[o] = p;
+                        if (target) {
+                            const float w = tw ? tw[b * K + k] : 1.f;
+                            const float d = w * (p - target[o]);
+                            part += d * d;
+                            g8[j] = (bf16)(2.f * w * d * coef);
+                        }
+                    }
+                }
             }
+            if (dp) *reinterpret_cast<bf16x8*>(dp + k0) = g8;
         }
-        if (dp)
-            for (int k = K; k < ldh; ++k) dp[k] = (bf16)0.f;
     }
     if (target && loss) {
         part = wave_sum(part);
@@ -360,7 +374,8 @@ extern "C" int vp_bn_bwd(const void* g, const void* z, const float* mean, const 
 
 extern "C" int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, const float* target, const float* tw,
                                float* loss, void* dheat, int B, int K, int HW, float loss_weight, hipStream_t stream) {
-    VP_CHECK_ARG(heat && B > 0 && K > 0 && K <= ldh && HW > 0);
+    VP_CHECK_ARG(heat && B > 0 && K > 0 && K <= ldh && HW > 0 && ldh % 8 == 0);
+    VP_CHECK_ARG(((uintptr_t)heat & 15) == 0 && ((uintptr_t)dheat & 15) == 0);
     VP_CHECK_ARG(heat_nchw || target);
     const float coef = loss_weight / ((float)B * (float)K * (float)HW);
     const size_t n = (size_t)B * HW;
