@@ -11,7 +11,8 @@ Units and corrections: both counters are reported in KiB.  On gfx950 FETCH_SIZE 
 requests of wide coalesced reads (16 B per lane, plain loads and LDS-DMA alike) at 64 bytes, i.e. it
 reports one half of the bytes: fetch bytes = 2 x FETCH_SIZE x 1024.  WRITE_SIZE is exact for
 16-byte-per-lane stores: write bytes = WRITE_SIZE x 1024.  Other access widths are uncalibrated.
-The launcher vp_gemm_bf16 picks one of three tile-schedule kernels per shape; rows are keyed both by
+The launcher vp_gemm_bf16 picks one of four tile-schedule kernels per shape (vp_wgrad_grouped_bf16 runs
+gemm192_kernel / gemm256_kernel<true, true, 5>); rows are keyed both by
 the device kernel name and by the launcher instantiation vp_gemm_bf16<x_kmajor, y_kmajor, epilogue>."""
 import csv
 import json
@@ -46,8 +47,16 @@ def main():
         res[short] = dict(launches=n, fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
                           hbm_bytes_per_launch=round(fb + wb))
         m = re.match(r'gemm(?:192|256)?_kernel<(true|false), (true|false), (\d+)>', short)
+        key = None
         if m:
-            g = groups.setdefault(f'vp_gemm_bf16<{m.group(1)}, {m.group(2)}, {m.group(3)}>', [0, 0.0, 0.0])
+            key = f'vp_gemm_bf16<{m.group(1)}, {m.group(2)}, {m.group(3)}>'
+            if m.group(1) == 'true' and m.group(2) == 'true' and m.group(3) == '5' and 'gemm_kernel' not in short:
+                key = 'vp_wgrad_grouped_bf16'      # the grouped launcher is the only user of this instantiation
+        m2 = re.match(r'gemm_w2_kernel<(true|false), (\d+)>', short)
+        if m2:
+            key = f'vp_gemm_bf16<false, {m2.group(1)}, {m2.group(2)}>'
+        if key:
+            g = groups.setdefault(key, [0, 0.0, 0.0])
             g[0] += n
             g[1] += fb * n
             g[2] += wb * n

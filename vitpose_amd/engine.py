@@ -438,10 +438,14 @@ class VitRunner:
                 plan.join()
                 after_block(plan, i)
         # ---- patch embedding + position embedding
+        # (on its own: 16 more tiles would push the last group of 4 Blocks, 768 tiles = 3 whole rounds of the
+        # chip, into a fourth round)
+        flush()
         plan.fork()
         with plan.on_side():
-            defer(dxb, ws.bufs['pe_col'], 'patch_embed.proj.weight', E, self.Kpe)
-        flush()
+            pslab = ws.f32('splitk_slab_patch', 32 * E * self.Kpe)
+            plan.wgrad(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
+                       split_k=_split_k(E, self.Kpe, M), slab=pslab)
         plan.batch_sum(dx, self.dpos, B, T * E)
         gp = self.g('pos_embed')[0]
 
