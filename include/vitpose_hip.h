@@ -185,6 +185,17 @@ int vp_relu_bf16(const void* x, void* y, size_t n, vp_stream_t stream);
  * head fed by a foreign NCHW backbone, and of NCHW heat-map gradients (vit.py:330 is the inverse). */
 int vp_nchw_to_cl_bf16(const float* src, void* dst_bf16, int B, int C, int HW, int ld, vp_stream_t stream);
 
+/* ConvTranspose2d(k=4, s=2, p=1, bias=False) forward (topdown_heatmap_simple_head.py:306-337, the deconv layers)
+ * on channels-last bf16 in ONE launch: the four output parities are four implicit GEMMs whose X operand (the
+ * sub-pixel im2col of `in`) is gathered on the fly, never materialised.  in [B*H*W][C]; wph [4][Cout][4*C] = the
+ * phase matrices wph[py*2+px][co][(ty*2+tx)*C + ci] = W[ci][co][(1-py)+2ty][(1-px)+2tx]; out [B*2H*2W][Cout] bf16.
+ * epilogue VP_EPI_BF16 (training: raw conv output for the batch statistics) or VP_EPI_SCALE_RELU
+ * (eval: out = relu(acc * colscale + shift), BatchNorm folded).  zero_page: >= 128 bytes of zeros on the device
+ * (source of the taps that fall outside the image).  C % 64 == 0, Cout % 8 == 0. */
+int vp_deconv_fwd_bf16(const void* in_bf16, const void* wph_bf16, void* out_bf16, int B, int H, int W, int C, int Cout,
+                       int epilogue, const float* colscale, const float* shift, const void* zero_page,
+                       vp_stream_t stream);
+
 /* Grouped weight gradients: several independent dW_i [M_i][N_i] = x_i^T y_i (x_i [K][M_i], y_i [K][N_i], bf16,
  * reduction-major, f32 out, no K split) with one common reduction extent K (= tokens) in ONE launch, so that the
  * tiles of all problems together fill the chip in whole rounds (the Linear weight gradients of several Blocks,

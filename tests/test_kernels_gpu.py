@@ -262,6 +262,34 @@ def test_deconv_as_subpixel_gemms(dev):
     assert torch.equal(dwd.view(Ci, 16, Co).permute(0, 2, 1).reshape(Ci, Co, 4, 4), wr.grad)
 
 
+@pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 16, 12, 64, 64), (3, 16, 12, 128, 256), (1, 5, 7, 64, 40)])
+def test_deconv_fwd_fused_implicit_im2col(dev, B, H, W, Ci, Co):
+    """ConvTranspose2d(k4, s2, p1) forward in one launch (four parities, gathered X operand): exact on
+    integer data against torch, both epilogues; partial tiles in rows and columns."""
+    from vitpose_amd import _lib
+    x = ints((B, Ci, H, W), dev, -2, 3, seed=1)
+    wt = ints((Ci, Co, 4, 4), dev, -2, 3, seed=2)
+    ref = torch.nn.functional.conv_transpose2d(x, wt, stride=2, padding=1)
+    xcl = x.permute(0, 2, 3, 1).contiguous().bfloat16().view(B * H * W, Ci)
+    wph = torch.empty(4, Co, 4 * Ci, device=dev, dtype=torch.bfloat16)
+    out = torch.full((B * 4 * H * W, Co), float('nan'), device=dev, dtype=torch.bfloat16)
+    out2 = torch.full_like(out, float('nan'))
+    cs, sh = rnd((Co,), dev, 3).abs() / 16, rnd((Co,), dev, 4)
+
+    def fwd(p):
+        for py in range(2):
+            for px in range(2):
+                p.strided_cast(wt.view(-1)[(1 - py) * 4 + (1 - px):], wph[py * 2 + px], (Co, 2, 2, Ci),
+                               (16, 8, 2, Co * 16))
+        p.deconv_fwd(xcl, wph, out, B, H, W, Ci, Co)
+        p.deconv_fwd(xcl, wph, out2, B, H, W, Ci, Co, epilogue=_lib.VP_EPI_SCALE_RELU, colscale=cs, shift=sh)
+    run(fwd)
+    got = out.float().view(B, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)
+    assert torch.equal(got, ref.bfloat16().float())
+    want2 = torch.relu(ref * cs.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    torch.testing.assert_close(out2.float().view(B, 2 * H, 2 * W, Co).permute(0, 3, 1, 2), want2, rtol=1e-2, atol=1e-2)
+
+
 def test_batchnorm_relu_fwd_bwd(dev):
     M, C = 2 * 32 * 24, 256
     z = (rnd((M, C), dev, 1) * 1.5 + 0.3).bfloat16()

@@ -463,9 +463,61 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tail_fixup(int M, int N, int ti
 constexpr int W_BM = 192, W_BN = 128;
 constexpr int W_XBYTES = W_BM * BK * 2, W_YBYTES = W_BN * BK * 2;   // 24 KiB + 16 KiB per stage
 
-template <bool YKMAJ, int EPI>
+// Implicit sub-pixel im2col of a ConvTranspose2d(k=4, s=2, p=1): the X operand of output parity (py, px) is
+//   X[(b, y, x)][t * C + c] = in[b][y + dy(py, ty)][x + dx(px, tx)][c]   (0 outside), t = ty * 2 + tx,
+//   dy(0, {0, 1}) = {0, -1}, dy(1, {0, 1}) = {+1, 0}
+// and is never written to memory: the LDS-DMA source address of a tile row is the shifted pixel's channel
+// vector, or a page of zeros.  A 64-wide K step lies inside one tap (C % 64 == 0).
+struct Gather {
+    int H, W, C;
+    const bf16* zero;   // >= 128 bytes of zeros
+};
+
+struct GatherRows {      // per lane: the 6 tile rows it fetches (one per LDS-DMA round)
+    int pix[6];          // pixel index of the row (clamped to the last row of the operand)
+    int ok[6];           // bit t: tap t of this pixel lies inside the image
+};
+
+__device__ __forceinline__ GatherRows gather_rows(const Gather& g, int r0, int rows, int py, int px, int wave,
+                                                  int lane) {
+    GatherRows gr;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int L = (i * 4 + wave) * 64 + lane;
+        int row = r0 + (L >> 3);
+        row = row < rows ? row : rows - 1;
+        const int x = row % g.W, y = (row / g.W) % g.H;
+        int ok = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = t >> 1, tx = t & 1;
+            const int yy = y + (py ? 1 - ty : -ty), xx = x + (px ? 1 - tx : -tx);
+            ok |= (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) << t;
+        }
+        gr.pix[i] = row;
+        gr.ok[i] = ok;
+    }
+    return gr;
+}
+
+__device__ __forceinline__ void stage_tile_gather(const bf16* in, const Gather& g, const GatherRows& gr, int k0,
+                                                  int py, int px, char* lds, int wave, int lane) {
+    const int t = k0 / g.C, c0 = k0 - t * g.C;            // wave-uniform
+    const int ty = t >> 1, tx = t & 1;
+    const int shift = (py ? 1 - ty : -ty) * g.W + (px ? 1 - tx : -tx);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int base = (i * 4 + wave) * 64, L = base + lane;
+        const int r = L >> 3, c = (L & 7) ^ (r & 7);
+        const bf16* src = ((gr.ok[i] >> t) & 1) ? in + (size_t)(gr.pix[i] + shift) * g.C + c0 + c * 8 : g.zero + c * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
+    }
+}
+
+template <bool YKMAJ, int EPI, bool GATHER = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand Y, int M, int N, int K, int tiles_n,
-                                                              int ntiles, Epi e) {
+                                                              int ntiles, Epi e, Gather gth = Gather{}) {
     __shared__ __attribute__((aligned(16))) char lds[2][W_XBYTES + W_YBYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -483,14 +535,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage_tile<false, W_BM>(X, i0, 0, lds[0], wave, lane);
+    // GATHER: blockIdx.y = output parity (py, px) of the transposed conv; Y and the output rows follow it
+    int py = 0, px = 0;
+    GatherRows gr;
+    if constexpr (GATHER) {
+        py = blockIdx.y >> 1;
+        px = blockIdx.y & 1;
+        Y.p += (size_t)blockIdx.y * Y.rows * Y.ld;
+        e.row_div = gth.W;
+        e.row_hi = 4 * gth.W;
+        e.row_lo = 2;
+        e.row_off = py * 2 * gth.W + px;
+        gr = gather_rows(gth, i0, M, py, px, wave, lane);
+    }
+    auto stage_x = [&](int k0, char* dst) {
+        if constexpr (GATHER) stage_tile_gather(X.p, gth, gr, k0, py, px, dst, wave, lane);
+        else stage_tile<false, W_BM>(X, i0, k0, dst, wave, lane);
+    };
+    stage_x(0, lds[0]);
     stage_tile<YKMAJ>(Y, j0, 0, lds[0] + W_XBYTES, wave, lane);
     __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            stage_tile<false, W_BM>(X, i0, (kt + 1) * BK, lds[cur ^ 1], wave, lane);
+            stage_x((kt + 1) * BK, lds[cur ^ 1]);
             stage_tile<YKMAJ>(Y, j0, (kt + 1) * BK, lds[cur ^ 1] + W_XBYTES, wave, lane);
         }
         const char* lx = lds[cur];
@@ -1205,5 +1274,31 @@ extern "C" int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count,
     else
         hipLaunchKernelGGL((gemm192_kernel<true, true, VP_EPI_F32>), dim3(total_tiles), dim3(T2_THREADS), 0, stream,
                            none, none, 0, 0, K, 1, 1, K / BK, e, table_dev, count);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_deconv_fwd_bf16(const void* in, const void* wph, void* out, int B, int H, int W, int C, int Cout,
+                                  int epilogue, const float* colscale, const float* shift, const void* zero_page,
+                                  hipStream_t stream) {
+    VP_CHECK_ARG(in && wph && out && zero_page && B > 0 && H > 0 && W > 0);
+    VP_CHECK_ARG(C % 64 == 0 && Cout % 8 == 0 && (epilogue == VP_EPI_BF16 || epilogue == VP_EPI_SCALE_RELU));
+    VP_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)wph & 15) == 0 && ((uintptr_t)out & 15) == 0);
+    const int M = B * H * W, K = 4 * C;
+    Operand X{(const bf16*)in, C, M}, Y{(const bf16*)wph, K, Cout};
+    Epi e{};
+    e.kind = epilogue;
+    e.out = out;
+    e.ldo = Cout;
+    e.bias = shift;
+    e.colscale = colscale;
+    Gather g{H, W, C, (const bf16*)zero_page};
+    const int tm = (M + W_BM - 1) / W_BM, tn = (Cout + W_BN - 1) / W_BN;
+    dim3 grid(tm * tn, 4);
+    if (epilogue == VP_EPI_BF16)
+        hipLaunchKernelGGL((gemm_w2_kernel<false, VP_EPI_BF16, true>), grid, dim3(NTHREADS), 0, stream, X, Y, M, Cout, K,
+                           tn, tm * tn, e, g);
+    else
+        hipLaunchKernelGGL((gemm_w2_kernel<false, VP_EPI_SCALE_RELU, true>), grid, dim3(NTHREADS), 0, stream, X, Y, M,
+                           Cout, K, tn, tm * tn, e, g);
     VP_LAUNCH_RET();
 }

@@ -9,6 +9,7 @@ evaluated as a GEMM on the low-resolution grid (one column block per conv tap) f
 interpolate-shift-sum kernel; the up-sampled feature map is never materialised.
 """
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -17,6 +18,7 @@ from . import _lib
 from .engine import ParamStore, Workspace, _slab_elems, _split_k
 from .plan import Plan
 
+FUSED_DECONV = os.environ.get('VITPOSE_FUSED_DECONV', '1') != '0'   # 0: explicit im2col + one GEMM per parity
 KPAD = 64  # the K=17 heat-map channels are padded to one 64-wide MFMA K step / 4 column tiles
 
 
@@ -254,21 +256,28 @@ class HeadRunner:
         for l in range(self.nl):
             ci, co = self.chans[l], self.chans[l + 1]
             Min, Mout = B * H * W, B * 4 * H * W
-            col = ws.bf16('dc_col', Min * 4 * ci)
             z = ws.bf16('z' + sfx(l) + ('' if training else f'_{l}'), Mout, co)
             bn = f'deconv_layers.{3 * l + 1}.'
             if not training:
                 plan.bn_finalize(None, Mout, co, self.w(bn + 'weight'), self.w(bn + 'bias'),
                                  self.buf(bn + 'running_mean'), self.buf(bn + 'running_var'), 0.1, 1e-5,
                                  self.bn_scale[l], self.bn_shift[l], None, None)
-            for py in range(2):
-                for px in range(2):
-                    plan.deconv_phase_im2col(a, col, B, H, W, ci, py, px)
-                    plan.gemm(col, self.wph[l][py * 2 + px], z, Min, co, 4 * ci, ldx=4 * ci, ldy=4 * ci, ldo=co,
-                              epilogue=_lib.VP_EPI_BF16 if training else _lib.VP_EPI_SCALE_RELU,
-                              colscale=None if training else self.bn_scale[l],
-                              bias=None if training else self.bn_shift[l],
-                              row_map=(W, 4 * W, 2, py * 2 * W + px))
+            if ci % 64 == 0 and FUSED_DECONV:
+                # the four output parities in one launch; the sub-pixel im2col is gathered inside the GEMM
+                plan.deconv_fwd(a, self.wph[l], z, B, H, W, ci, co,
+                                epilogue=_lib.VP_EPI_BF16 if training else _lib.VP_EPI_SCALE_RELU,
+                                colscale=None if training else self.bn_scale[l],
+                                shift=None if training else self.bn_shift[l])
+            else:
+                col = ws.bf16('dc_col', Min * 4 * ci)
+                for py in range(2):
+                    for px in range(2):
+                        plan.deconv_phase_im2col(a, col, B, H, W, ci, py, px)
+                        plan.gemm(col, self.wph[l][py * 2 + px], z, Min, co, 4 * ci, ldx=4 * ci, ldy=4 * ci, ldo=co,
+                                  epilogue=_lib.VP_EPI_BF16 if training else _lib.VP_EPI_SCALE_RELU,
+                                  colscale=None if training else self.bn_scale[l],
+                                  bias=None if training else self.bn_shift[l],
+                                  row_map=(W, 4 * W, 2, py * 2 * W + px))
             if training:
                 plan.memset0(self.bn_sums[l])
                 plan.bn_stats(z, self.bn_sums[l], Mout, co)

@@ -53,6 +53,17 @@ def _time_launch(fn, reps=4):
     return e0.elapsed_time(e1) / reps
 
 
+_ZERO_PAGES = {}
+
+
+def _zero_page(device):
+    """256 zero bytes per device: the source of out-of-image taps of the implicit im2col."""
+    key = str(device)
+    if key not in _ZERO_PAGES:
+        _ZERO_PAGES[key] = torch.zeros(128, dtype=torch.bfloat16, device=device)
+    return _ZERO_PAGES[key]
+
+
 def _tail_workspace(device):
     """One 32 MiB scratch per device for the GEMM tail-tile partial sums (launches are stream-ordered)."""
     key = (device.type, device.index)
@@ -358,6 +369,11 @@ class Plan:
 
     def batch_sum(self, x, out, B, n):
         self._add('vp_batch_sum_f32', _p(x), _p(out), B, n, keep=(x, out))
+
+    def deconv_fwd(self, src, wph, out, B, H, W, C, Cout, epilogue=_lib.VP_EPI_BF16, colscale=None, shift=None):
+        zero = _zero_page(src.device)
+        self._add('vp_deconv_fwd_bf16', _p(src), _p(wph), _p(out), B, H, W, C, Cout, epilogue, _p(colscale), _p(shift),
+                  _p(zero), keep=(src, wph, out, colscale, shift, zero))
 
     def deconv_phase_im2col(self, src, col, B, H, W, C, py, px):
         self._add('vp_deconv_phase_im2col', _p(src), _p(col), B, H, W, C, py, px, keep=(src, col))
