@@ -294,8 +294,6 @@ class Plan:
                 raise KernelError(f'vp_wgrad_group_table -> {rc}')
             blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             return blob, total.value
-        if tile_mode == 0 and any(len(p) > 7 and p[7] is not None for p in problems):
-            tile_mode = 3       # the 256-tile kernel has no registers left for the row-sum accumulators (it spills)
         if tile_mode == 0:
             key = ('wgrad_group', tuple((p[3], p[4]) for p in problems), K, str(dev))
             if AUTOTUNE and key not in _TUNE_CACHE:
