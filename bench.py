@@ -13,7 +13,7 @@ logs every 50 iterations is not part of the step (`train_cfg.skip_accuracy`).
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-  python bench.py --mode infer --model B --batch 64      (BASELINE config 2: one eval forward)
+  python bench.py --mode infer --model B --batch 64      (the inference configuration of the headline benchmark: one eval forward)
 
 Rank 0 prints ONE JSON line.
 """

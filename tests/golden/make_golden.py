@@ -102,7 +102,7 @@ def vitpose_s_eval():
         feat = m(img)
         heat = h(feat)
     save('vitpose_s_classic_eval.npz', feat_sub=feat[:, ::8], heat=heat)
-    # simple decoder, batch 1 (BASELINE config 1)
+    # simple decoder, batch 1 (the CPU-runnable configuration of the headline benchmark)
     hs = O.simple_head_cfg(384)
     hsd = O.synth_head_weights(hs, seed=23)
     h2 = build_ref_head(hs, hsd).eval()

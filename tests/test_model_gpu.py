@@ -202,7 +202,7 @@ def test_train_step_updates_weights_like_torch_adamw(dev):
 
 
 def test_vitpose_s_simple_decoder_vs_reference_golden(dev, golden_dir):
-    """BASELINE config 1 (ViTPose-S + simple decoder, batch 1): the reference source ran it on the
+    """The CPU-runnable benchmark configuration (ViTPose-S + simple decoder, batch 1): the reference source ran it on the
     CPU (golden), the HIP path runs it on the GPU.  O(1) heat maps, bf16 operands: relative bound."""
     g = np.load(os.path.join(golden_dir, 'vitpose_s_simple_eval.npz'))
     vcfg, hs = O.vit_cfg('S'), O.simple_head_cfg(384)
