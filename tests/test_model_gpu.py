@@ -343,3 +343,31 @@ def test_ddp_plan_on_gpu_single_rank_group(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_wholebody_133_keypoints_train_step_and_eval(dev):
+    """COCO-WholeBody heads (133 heat maps, configs/wholebody/.../ViTPose_*_wholebody_256x192.py): the channel
+    padding follows the keypoint count.  Forward + backward and the eval forward against the oracle."""
+    hc = dict(O.classic_head_cfg(64), out_channels=133)
+    bb, hd = O.synth_vit_weights(TOY, seed=5), O.synth_head_weights(hc, seed=6)
+    eng = make_engine(TOY, hc, bb, hd, dev)
+    img, target, tw = O.synth_batch(2, K=133, seed=7)
+    loss, heat = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+    torch.cuda.synchronize()
+    assert heat.shape == (2, 133, 64, 48)
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    hdr = {k: v.clone().requires_grad_() if v.dtype.is_floating_point and 'running' not in k else v.clone()
+           for k, v in hd.items()}
+    ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), hc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
+    for n in ('final_layer.weight', 'final_layer.bias', 'deconv_layers.3.weight'):
+        assert relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0] < 0.12, n
+    assert relerr(eng.store.gview('backbone.blocks.1.mlp.fc2.weight'), bbr['blocks.1.mlp.fc2.weight'].grad)[0] < 0.12
+    with torch.no_grad():
+        ref_eval = O.topdown_forward(bb, hd, img, TOY, hc)
+    ev = make_engine(TOY, hc, bb, hd, dev)      # fresh BatchNorm running statistics (the train step moved eng's)
+    assert relerr(ev.infer(img.to(dev)), ref_eval)[0] < 3e-2
+    assert (ev.infer(img.to(dev), exact=True).cpu() - ref_eval).abs().max().item() < 1e-3 * max(1.0, ref_eval.abs().max().item())

@@ -19,7 +19,7 @@ from .engine import ParamStore, Workspace, _slab_elems, _split_k
 from .plan import Plan
 
 FUSED_DECONV = os.environ.get('VITPOSE_FUSED_DECONV', '1') != '0'   # 0: explicit im2col + one GEMM per parity
-KPAD = 64  # the K=17 heat-map channels are padded to one 64-wide MFMA K step / 4 column tiles
+KPAD = 64  # heat-map channels (17 COCO ... 133 COCO-WholeBody) are padded to whole 64-wide MFMA K steps
 
 
 def head_param_shapes(cfg) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[Tuple[str, Tuple[int, ...]]]]:
@@ -94,8 +94,7 @@ class HeadRunner:
                 raise NotImplementedError('deconv head with final_conv_kernel != 1 or upsample')
         if self.fk not in (1, 3):
             raise NotImplementedError('HIP head needs a final conv (final_conv_kernel 1 or 3)')
-        if self.K > KPAD:
-            raise NotImplementedError('more than 64 keypoints')
+        self.kpad = (self.K + KPAD - 1) // KPAD * KPAD
         dev = store.device
         self.simple = self.nl == 0 and (self.fk == 3 or self.upsample > 0)
         if self.simple:
@@ -110,10 +109,10 @@ class HeadRunner:
         self.dwd = [torch.zeros(self.chans[l], 16 * self.chans[l + 1], dtype=torch.float32, device=dev)
                     for l in range(self.nl)]
         cl = self.chans[-1]
-        self.wf = torch.zeros(KPAD, cl, dtype=torch.bfloat16, device=dev)
-        self.bf = torch.zeros(KPAD, dtype=torch.float32, device=dev)
-        self.dwf = torch.zeros(KPAD, cl, dtype=torch.float32, device=dev)
-        self.dbf = torch.zeros(KPAD, dtype=torch.float32, device=dev)
+        self.wf = torch.zeros(self.kpad, cl, dtype=torch.bfloat16, device=dev)
+        self.bf = torch.zeros(self.kpad, dtype=torch.float32, device=dev)
+        self.dwf = torch.zeros(self.kpad, cl, dtype=torch.float32, device=dev)
+        self.dbf = torch.zeros(self.kpad, dtype=torch.float32, device=dev)
         self.bn_scale = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
         self.bn_shift = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
         self.bn_mean = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
@@ -126,6 +125,8 @@ class HeadRunner:
         s = self.upsample if self.upsample > 0 else 1
         self.Ho, self.Wo = int(self.Hg * s), int(self.Wg * s)
         self.taps = self.fk * self.fk
+        if self.K > 64:
+            raise NotImplementedError('simple decoder with more than 64 keypoints')
         self.kp = 20 if self.K <= 20 else (32 if self.K <= 32 else 64)   # per-tap columns of G
         self.ng = self.taps * self.kp                                  # valid columns of G
         self.ngp = (self.ng + 63) // 64 * 64                           # as a reduction extent
@@ -239,9 +240,9 @@ class HeadRunner:
             H, W = 2 * H, 2 * W
         Mh = B * H * W
         cl = self.chans[-1]
-        heat = ws.f32('xh_heat_cl', Mh, KPAD)
-        plan.gemm3(ah, al, self.wf, self.wf_lo, heat, Mh, KPAD, cl, ldx=cl, ldy=cl, ldo=KPAD, bias=self.bf)
-        plan.heatmap_loss(heat, KPAD, heat_nchw, None, None, None, None, B, self.K, H * W, 1.0)
+        heat = ws.f32('xh_heat_cl', Mh, self.kpad)
+        plan.gemm3(ah, al, self.wf, self.wf_lo, heat, Mh, self.kpad, cl, ldx=cl, ldy=cl, ldo=self.kpad, bias=self.bf)
+        plan.heatmap_loss(heat, self.kpad, heat_nchw, None, None, None, None, B, self.K, H * W, 1.0)
 
     # -- forward --
     def record_forward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, B: int, training: bool,
@@ -292,12 +293,12 @@ class HeadRunner:
             H, W = 2 * H, 2 * W
         Mh = B * H * W
         cl = self.chans[-1]
-        heat = ws.f32('heat_cl', Mh, KPAD)
-        plan.gemm(a, self.wf, heat, Mh, KPAD, cl, ldx=cl, ldy=cl, ldo=KPAD, epilogue=_lib.VP_EPI_F32, bias=self.bf)
-        dheat = ws.bf16('dheat', Mh, KPAD) if want_grad else None
+        heat = ws.f32('heat_cl', Mh, self.kpad)
+        plan.gemm(a, self.wf, heat, Mh, self.kpad, cl, ldx=cl, ldy=cl, ldo=self.kpad, epilogue=_lib.VP_EPI_F32, bias=self.bf)
+        dheat = ws.bf16('dheat', Mh, self.kpad) if want_grad else None
         if loss is not None:
             plan.memset0(loss)
-        plan.heatmap_loss(heat, KPAD, heat_nchw, target, tw, loss, dheat, B, self.K, H * W, loss_weight)
+        plan.heatmap_loss(heat, self.kpad, heat_nchw, target, tw, loss, dheat, B, self.K, H * W, loss_weight)
         self._last_act = a
         self.out_hw = (H, W)
         return dheat
@@ -350,8 +351,8 @@ class HeadRunner:
         if self.simple:
             return self._record_backward_simple(plan, ws, feat, dheat_nchw, B)
         H, W = self.out_hw
-        dheat = ws.bf16('dheat', B * H * W, KPAD)
-        plan.nchw_to_cl(dheat_nchw, dheat, B, self.K, H * W, KPAD)
+        dheat = ws.bf16('dheat', B * H * W, self.kpad)
+        plan.nchw_to_cl(dheat_nchw, dheat, B, self.K, H * W, self.kpad)
         return self.record_backward(plan, ws, feat, dheat, B)
 
     # -- backward: returns the bf16 gradient wrt `feat` --
@@ -364,10 +365,10 @@ class HeadRunner:
         a_last = ws.bufs[f'a.{self.nl - 1}'] if self.nl else feat
         # final 1x1 conv
         slab = ws.f32('splitk_slab_head', _slab_elems(max(self.chans[l] * 16 * self.chans[l + 1]
-                                                          for l in range(self.nl)) if self.nl else KPAD * cl, Mh))
+                                                          for l in range(self.nl)) if self.nl else self.kpad * cl, Mh))
         plan.memset0(self.dbf)
-        plan.wgrad(dheat, a_last, self.dwf, KPAD, cl, Mh, ldx=KPAD, ldy=cl, split_k=_split_k(KPAD, cl, Mh), slab=slab)
-        plan.colsum(dheat, self.dbf, Mh, KPAD, KPAD)
+        plan.wgrad(dheat, a_last, self.dwf, self.kpad, cl, Mh, ldx=self.kpad, ldy=cl, split_k=_split_k(self.kpad, cl, Mh), slab=slab)
+        plan.colsum(dheat, self.dbf, Mh, self.kpad, self.kpad)
         gW, gb, dwf, dbf, K = self.g('final_layer.weight'), self.g('final_layer.bias'), self.dwf, self.dbf, self.K
 
         def final_grads():
@@ -376,9 +377,9 @@ class HeadRunner:
         plan.host(final_grads)
         g = ws.bf16('hg', Mh, cl)
         if self.nl == 0:
-            plan.gemm(dheat, self.wf, g, Mh, cl, KPAD, ldx=KPAD, ldy=cl, ldo=cl, y_kmajor=True)
+            plan.gemm(dheat, self.wf, g, Mh, cl, self.kpad, ldx=self.kpad, ldy=cl, ldo=cl, y_kmajor=True)
             return g
-        plan.gemm(dheat, self.wf, g, Mh, cl, KPAD, ldx=KPAD, ldy=cl, ldo=cl, y_kmajor=True,
+        plan.gemm(dheat, self.wf, g, Mh, cl, self.kpad, ldx=self.kpad, ldy=cl, ldo=cl, y_kmajor=True,
                   epilogue=_lib.VP_EPI_DRELU, aux=a_last, ldaux=cl)
         for l in range(self.nl - 1, -1, -1):
             ci, co = self.chans[l], self.chans[l + 1]
