@@ -276,6 +276,9 @@ class Plan:
         reduction extent K.  problems: list of (x [K][M] bf16, y [K][N] bf16, out f32, M, N, ldx, ldy[, rowsum]);
         rowsum (f32 [M], optional) receives sum_k x[k][m], the bias gradient of the same Linear."""
         from ._lib import GroupEntry
+        if len(problems) > 64:               # the kernel maps a workgroup to its problem with one 64-lane ballot
+            self.wgrad_group(problems[:64], K, tile_mode)
+            return self.wgrad_group(problems[64:], K, tile_mode)
         n = len(problems)
         dev = problems[0][2].device
 
