@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 class GradBuckets:
     def __init__(self, store, backbone_prefix='backbone.', head_prefix='keypoint_head.', depth=12,
-                 blocks_per_bucket=4, process_group=None):
+                 blocks_per_bucket=4, process_group=None, split_tail=True):
         self.store = store
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -48,7 +48,13 @@ class GradBuckets:
             self.triggers[lo_blk] = (self.bounds[lo_blk], hi)
             hi = self.bounds[lo_blk]
             i = lo_blk - 1
-        self.tail = (0, hi)  # the first (up to blocks_per_bucket) blocks + patch/pos embedding: when backward ends
+        # the last bucket cannot overlap anything (backward is over when it is final), so the remaining
+        # blocks are cut once more: only the lower half + patch/pos embedding is sent after backward ends
+        if split_tail and i >= 3:
+            lo_blk = (i + 1) // 2
+            self.triggers[lo_blk] = (self.bounds[lo_blk], hi)
+            hi = self.bounds[lo_blk]
+        self.tail = (0, hi)
 
     # -- called from plan.host closures (i.e. in stream order of the compute stream) --
     def _launch(self, lo, hi):
