@@ -196,6 +196,11 @@ int vp_deconv_fwd_bf16(const void* in_bf16, const void* wph_bf16, void* out_bf16
                        int epilogue, const float* colscale, const float* shift, const void* zero_page,
                        vp_stream_t stream);
 
+/* Both compute layouts of a ConvTranspose2d(k=4) weight W [Ci][Co][4][4] (f32 master) in one pass: the phase
+ * matrices wph [4][Co][4*Ci] of vp_deconv_fwd_bf16 and the 16-tap matrix wd [Ci][16*Co] the data gradient reads
+ * (wd[ci][(ky*4+kx)*Co + co] = W[ci][co][ky][kx]); both bf16.  Replaces five vp_strided_cast launches per layer. */
+int vp_deconv_weight_prep(const float* w, void* wph_bf16, void* wd_bf16, int Ci, int Co, vp_stream_t stream);
+
 /* Grouped weight gradients: several independent dW_i [M_i][N_i] = x_i^T y_i (x_i [K][M_i], y_i [K][N_i], bf16,
  * reduction-major, f32 out, no K split) with one common reduction extent K (= tokens) in ONE launch, so that the
  * tiles of all problems together fill the chip in whole rounds (the Linear weight gradients of several Blocks,

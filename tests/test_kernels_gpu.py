@@ -652,3 +652,17 @@ def test_gemm_w2_epilogues(dev):
     with pytest.raises(Exception):                 # k-major x is outside this schedule
         run(lambda p: p.gemm(bad, Y, o32, M, N, K, ldx=M, ldy=K, ldo=N, x_kmajor=True, epilogue=_lib.VP_EPI_F32,
                              tile_mode=4))
+
+
+@pytest.mark.parametrize('Ci,Co', [(64, 64), (768, 256), (40, 72)])
+def test_deconv_weight_prep_layouts(dev, Ci, Co):
+    wt = rnd((Ci, Co, 4, 4), dev, 1)
+    wph = torch.full((4, Co, 4 * Ci), float('nan'), device=dev, dtype=torch.bfloat16)
+    wd = torch.full((Ci, 16 * Co), float('nan'), device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.deconv_weight_prep(wt, wph, wd, Ci, Co))
+    wb = wt.bfloat16()
+    assert torch.equal(wd.view(Ci, 16, Co), wb.view(Ci, Co, 16).permute(0, 2, 1))
+    for py in range(2):
+        for px in range(2):
+            want = wb[:, :, (1 - py)::2, (1 - px)::2]                  # [ci][co][ty][tx]
+            assert torch.equal(wph[py * 2 + px].view(Co, 2, 2, Ci), want.permute(1, 2, 3, 0))

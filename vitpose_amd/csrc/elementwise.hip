@@ -49,6 +49,54 @@ __global__ __launch_bounds__(256) void strided_cast_kernel(const TI* __restrict_
     }
 }
 
+// ---- compute layouts of a ConvTranspose2d(k=4) weight W [Ci][Co][4][4] f32, in one pass ----
+//   wph[py*2+px][co][(ty*2+tx)*Ci + ci] = W[ci][co][(1-py)+2ty][(1-px)+2tx]   (sub-pixel phase matrices, forward)
+//   wd[ci][(ky*4+kx)*Co + co]          = W[ci][co][ky][kx]                     (16-tap matrix, data gradient)
+// One workgroup per 32 x 32 (ci, co) patch: read with co fastest (64 contiguous bytes per thread), stage as bf16
+// in LDS, write wph with ci fastest and wd with co fastest.
+__global__ __launch_bounds__(256) void deconv_weight_prep_kernel(const float* __restrict__ w, bf16* __restrict__ wph,
+                                                                 bf16* __restrict__ wd, int Ci, int Co) {
+    __shared__ bf16 tile[32][33][16];
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int cl = i >> 5, ol = i & 31;           // co fastest
+        const int ci = ci0 + cl, co = co0 + ol;
+        if (ci < Ci && co < Co) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(w + ((size_t)ci * Co + co) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = src[q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[cl][ol][q * 4 + r] = (bf16)v[r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        {   // wd: co fastest
+            const int cl = i >> 5, ol = i & 31;
+            const int ci = ci0 + cl, co = co0 + ol;
+            if (ci < Ci && co < Co) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) wd[(size_t)ci * 16 * Co + (size_t)t * Co + co] = tile[cl][ol][t];
+            }
+        }
+        {   // wph: ci fastest
+            const int ol = i >> 5, cl = i & 31;
+            const int ci = ci0 + cl, co = co0 + ol;
+            if (ci < Ci && co < Co) {
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int ky = (1 - (ph >> 1)) + 2 * (t >> 1), kx = (1 - (ph & 1)) + 2 * (t & 1);
+                        wph[((size_t)ph * Co + co) * 4 * Ci + (size_t)t * Ci + ci] = tile[cl][ol][ky * 4 + kx];
+                    }
+            }
+        }
+    }
+}
+
 // ---- column sums of a bf16 [M][N] matrix into f32 [N] (atomic accumulate) ----
 // block = 256 threads = 32 column-chunks (8 cols) x 8 row lanes; grid.x tiles columns, grid.y rows.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ a, float* __restrict__ out, int M, int N,
@@ -213,5 +261,12 @@ extern "C" int vp_deconv_out_gather16(const void* dout, void* g, int B, int H, i
     const size_t total = (size_t)B * H * W * (16 * C / 8);
     hipLaunchKernelGGL(deconv_out_gather16_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16*)dout,
                        (bf16*)g, B, H, W, C);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_deconv_weight_prep(const float* w, void* wph, void* wd, int Ci, int Co, hipStream_t stream) {
+    VP_CHECK_ARG(w && wph && wd && Ci > 0 && Co > 0 && ((uintptr_t)w & 15) == 0);
+    hipLaunchKernelGGL(deconv_weight_prep_kernel, dim3((Co + 31) / 32, (Ci + 31) / 32), dim3(256), 0, stream, w,
+                       (bf16*)wph, (bf16*)wd, Ci, Co);
     VP_LAUNCH_RET();
 }

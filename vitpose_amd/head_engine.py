@@ -164,15 +164,9 @@ class HeadRunner:
                                   (0, 0, self.cin * self.taps, self.taps))
             return
         for l in range(self.nl):
-            W = self.w(f'deconv_layers.{3 * l}.weight')  # [Cin][Cout][4][4] f32
-            ci, co = self.chans[l], self.chans[l + 1]
-            for py in range(2):
-                for px in range(2):
-                    # wph[phase][co][(ty,tx,ci)] = W[ci][co][(1-py)+2ty][(1-px)+2tx]
-                    src = W.view(-1)[(1 - py) * 4 + (1 - px):]
-                    plan.strided_cast(src, self.wph[l][py * 2 + px], (co, 2, 2, ci), (16, 8, 2, co * 16))
-            # wd[ci][(ky,kx,co)] = W[ci][co][ky][kx]
-            plan.strided_cast(W, self.wd[l], (ci, 16, co, 1), (co * 16, 1, 16, 0))
+            # wph[phase][co][(ty,tx,ci)] = W[ci][co][(1-py)+2ty][(1-px)+2tx]; wd[ci][(ky,kx,co)] = W[ci][co][ky][kx]
+            plan.deconv_weight_prep(self.w(f'deconv_layers.{3 * l}.weight'), self.wph[l], self.wd[l],
+                                    self.chans[l], self.chans[l + 1])
         Wf = self.w('final_layer.weight')  # [K][C][1][1]
         plan.strided_cast(Wf, self.wf, (1, 1, 1, Wf.numel()), (0, 0, 0, 1))
         bf, b = self.bf, self.w('final_layer.bias')

@@ -385,6 +385,10 @@ class Plan:
         self._add('vp_deconv_fwd_bf16', _p(src), _p(wph), _p(out), B, H, W, C, Cout, epilogue, _p(colscale), _p(shift),
                   _p(zero), keep=(src, wph, out, colscale, shift, zero))
 
+    def deconv_weight_prep(self, w, wph, wd, Ci, Co):
+        _chk(w, torch.float32, 'w')
+        self._add('vp_deconv_weight_prep', _p(w), _p(wph), _p(wd), Ci, Co, keep=(w, wph, wd))
+
     def deconv_phase_im2col(self, src, col, B, H, W, C, py, px):
         self._add('vp_deconv_phase_im2col', _p(src), _p(col), B, H, W, C, py, px, keep=(src, col))
 
