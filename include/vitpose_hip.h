@@ -219,6 +219,25 @@ int vp_wgrad_group_table(vp_group_entry* problems_host, int count, int tile_mode
 int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K, int tile_mode,
                           vp_stream_t stream);
 
+/* --------------------------------------------------------------- Input side ------
+ * vp_warp_affine_normalize: TopDownAffine's cv2.warpAffine(img, trans, image_size, INTER_LINEAR)
+ *   (datasets/pipelines/top_down_transform.py:312-363) + ToTensor + NormalizeTensor (shared_transform.py:21-64)
+ *   for a batch of 8-bit RGB images of different sizes: `imgs` = the images packed back to back (HWC bytes),
+ *   offsets [B] (bytes), hw [B][2] = (height, width), inv_matrices [B][6] f64 = the INVERTED 2x3 transforms
+ *   (destination -> source, what cv2 computes from `trans`), out [B][3][Ho][Wo] f32.  Restates OpenCV's
+ *   fixed-point bilinear scheme (1/32 px coordinates, 15-bit weights, constant border 0).
+ * vp_generate_target: TopDownGenerateTarget (top_down_transform.py:366-740) for encoding 0 = 'UDP' with
+ *   'GaussianHeatmap' targets (_udp_generate_target, :541-661), 1 = 'MSRA', 2 = 'MSRA' with unbiased_encoding
+ *   (_msra_generate_target, :418-492).  joints [B][K][3] (x, y in input-image pixels after the affine),
+ *   visible [B][K] (joints_3d_visible[:, 0]), joint_weights [K] or NULL (use_different_joint_weights),
+ *   target [B][K][H][W], target_weight [B][K]. */
+int vp_warp_affine_normalize(const unsigned char* imgs, const long* offsets, const int* hw, const double* inv_matrices,
+                             float* out, int B, int Ho, int Wo, const float mean[3], const float std[3],
+                             vp_stream_t stream);
+int vp_generate_target(const float* joints, const float* visible, const float* joint_weights, float* target,
+                       float* target_weight, int B, int K, int H, int W, int img_w, int img_h, float sigma,
+                       int encoding, vp_stream_t stream);
+
 /* ------------------------------------------------------------- Test-time decode ----
  * vp_flip_back_avg: out = (heat + flip_back(heat_flipped)) * 0.5 — flip_back (core/post_processing/
  *   post_transforms.py:54-95: swap the left/right joint channels, mirror the width axis; `perm[k]` = the

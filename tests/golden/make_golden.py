@@ -280,6 +280,30 @@ def decode():
     save('decode.npz', **out)
 
 
+def pipeline():
+    """get_warp_matrix / warp_affine_joints / TopDownGenerateTarget (UDP, MSRA, MSRA unbiased) of the reference
+    on the seeded samples of oracle/pipeline_oracle.py: synth_samples."""
+    from oracle import pipeline_oracle as P
+    K, image_size, heatmap_size = 17, np.array([192, 256]), np.array([48, 64])
+    samples = P.synth_samples(6, K=K, seed=80)
+    jw = np.linspace(1.0, 1.5, K).astype(np.float32).reshape(K, 1)
+    out = {}
+    for b, r in enumerate(samples):
+        trans = ref.get_warp_matrix(r['rotation'], r['center'] * 2.0, image_size - 1.0, r['scale'] * 200.0)
+        j = r['joints_3d'].copy()
+        j[:, 0:2] = ref.warp_affine_joints(j[:, 0:2].copy(), trans)
+        out[f'trans_{b}'], out[f'joints_{b}'] = trans, j
+        vis = np.stack([r['visible']] * 3, 1)
+        for tag, kw, diff in (('udp', dict(sigma=2, encoding='UDP'), False), ('msra', dict(sigma=2, encoding='MSRA'), True),
+                              ('msra_unb', dict(sigma=3, encoding='MSRA', unbiased_encoding=True), False)):
+            gen = ref.TopDownGenerateTarget(**kw)
+            res = gen(dict(joints_3d=j.copy(), joints_3d_visible=vis.copy(),
+                           ann_info=dict(num_joints=K, image_size=image_size, heatmap_size=heatmap_size,
+                                         joint_weights=jw, use_different_joint_weights=diff)))
+            out[f'{tag}_target_{b}'], out[f'{tag}_weight_{b}'] = res['target'], res['target_weight']
+    save('pipeline.npz', **out)
+
+
 if __name__ == '__main__':
     toy_vit()
     vitpose_s_eval()
@@ -287,3 +311,4 @@ if __name__ == '__main__':
     block_widths()
     misc()
     decode()
+    pipeline()

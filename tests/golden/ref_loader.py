@@ -175,7 +175,15 @@ def load_reference():
           'mmpose/models/heads/topdown_heatmap_base_head.py')
     head = _load('mmpose.models.heads.topdown_heatmap_simple_head',
                  'mmpose/models/heads/topdown_heatmap_simple_head.py')
+    # input-side transforms (numpy only, apart from the cv2 calls the fixtures never reach)
+    db = _mod('mmpose.datasets')
+    dbb = _mod('mmpose.datasets.builder')
+    dbb.PIPELINES = _Registry('pipeline')
+    db.builder = dbb
+    tdt = _load('mmpose.datasets.pipelines.top_down_transform', 'mmpose/datasets/pipelines/top_down_transform.py')
     ns = types.SimpleNamespace(
+        get_warp_matrix=post.get_warp_matrix, warp_affine_joints=post.warp_affine_joints,
+        TopDownGenerateTarget=tdt.TopDownGenerateTarget,
         ViT=vit.ViT, TopdownHeatmapSimpleHead=head.TopdownHeatmapSimpleHead,
         JointsMSELoss=loss.JointsMSELoss, pose_pck_accuracy=ev.pose_pck_accuracy,
         flip_back=post.flip_back, resize=ops.resize, _get_max_preds=ev._get_max_preds,

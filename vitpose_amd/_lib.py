@@ -70,6 +70,8 @@ SIGNATURES = {
     'vp_plane_sum_f32': [P, P, c_int, c_int, c_int, P],
     'vp_relu_bf16': [P, P, c_size_t, P],
     'vp_nchw_to_cl_bf16': [P, P, c_int, c_int, c_int, c_int, P],
+    'vp_warp_affine_normalize': [P, P, P, P, P, c_int, c_int, c_int, P, P, P],
+    'vp_generate_target': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P],
     'vp_flip_back_avg': [P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
     'vp_decode_heatmaps': [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P],
     'vp_finish_f32': [P, c_int, P, P, c_int, P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, P, P],
