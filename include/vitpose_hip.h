@@ -30,7 +30,7 @@ typedef void* vp_stream_t;
 typedef hipStream_t vp_stream_t;
 #endif
 
-#define VP_ABI_VERSION 1
+#define VP_ABI_VERSION 2
 int vp_abi_version(void);
 /* gfx target the library was compiled for, e.g. "gfx950". */
 const char* vp_build_arch(void);
@@ -83,6 +83,15 @@ typedef struct vp_gemm_args {
     int tile_mode;               /* 0: choose by shape; 1: 128x128 tiles (2 workgroups / CU); 2: 256x256 tiles (1 / CU);
                                     3: 192x192 tiles (1 / CU, three LDS stages); 4: 192x128 tiles, 2 workgroups / CU
                                     (k-contiguous x, no K split: VP_ERR_UNSUPPORTED otherwise) */
+    /* optional per-image routing of the Y operand: the mixture-of-experts FFN of ViTPose+ (MoEMlp.forward,
+     * mmpose/models/backbones/vit_moe.py:98-115: the last `part_features` output channels of fc2 come from the
+     * expert Linear selected by the image's dataset index).  Rows are images of exactly 192 tokens (M % 192 == 0);
+     * image b uses expert route_expert[b].  Y rows (y_kmajor = 0: output columns, the forward product;
+     * y_kmajor = 1: reduction rows, the data gradient) at or beyond route_split are read route_delta[expert]
+     * ELEMENTS further on than the shared matrix would hold them (a multiple of 8), and bias columns >= route_split
+     * route_bias_delta[expert] floats further on.  All three arrays live on the device.  Uses the 192 x 192 tile
+     * schedule; route_split % 48 == 0, k-contiguous x, no K split. */
+    const int* route_expert; const long* route_delta; const long* route_bias_delta; int route_split;
 } vp_gemm_args;
 
 int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);
@@ -214,10 +223,19 @@ typedef struct vp_group_entry {
     int ldx, ldy, ldo, M, N;
     int tiles_n, ntiles, tile0;   /* filled by vp_wgrad_group_table */
     float* rowsum;                /* optional [M]: rowsum[m] = sum_k x[k][m], the bias gradient of the same Linear */
-} vp_group_entry;                 /* 64 bytes */
+    /* vp_wgrad_grouped_kmap_bf16 only (else NULL): this problem reduces over a list of 64-row K tiles instead of
+     * all K rows: kmap[t] = first row of its t-th tile, *nk_dev = the number of tiles (device memory both, so a
+     * recorded launch follows per-step routing; 0 tiles = zeros are written). */
+    const int* kmap; const int* nk_dev;
+} vp_group_entry;                 /* 80 bytes */
 int vp_wgrad_group_table(vp_group_entry* problems_host, int count, int tile_mode, int* total_tiles);
 int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K, int tile_mode,
                           vp_stream_t stream);
+/* The same launch (192 x 192 tiles) for tables in which some problems carry a K-tile list: the expert weight
+ * gradients of the mixture-of-experts FFN (vit_moe.py:92-96,108-111 under autograd: expert e only receives
+ * gradient from the images routed to it).  K = rows of the operands (upper bound of every list). */
+int vp_wgrad_grouped_kmap_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K,
+                               vp_stream_t stream);
 
 /* --------------------------------------------------------------- Input side ------
  * vp_warp_affine_normalize: TopDownAffine's cv2.warpAffine(img, trans, image_size, INTER_LINEAR)

@@ -99,14 +99,29 @@ def attention(sd: Dict[str, Tensor], pre: str, x: Tensor, num_heads: int,
     return F.linear(o, sd[pre + 'proj.weight'], sd[pre + 'proj.bias'])
 
 
-def mlp(sd: Dict[str, Tensor], pre: str, x: Tensor, taps: Optional[dict] = None) -> Tensor:
-    """vit.py:71-76: fc2(GELU_erf(fc1(x)))  (nn.GELU default = exact erf)."""
+def mlp(sd: Dict[str, Tensor], pre: str, x: Tensor, taps: Optional[dict] = None,
+        indices: Optional[Tensor] = None) -> Tensor:
+    """vit.py:71-76: fc2(GELU_erf(fc1(x)))  (nn.GELU default = exact erf).
+    With expert weights in `sd` (ViTMoE), vit_moe.py:98-115 (MoEMlp.forward): fc2 emits the shared
+    channels, every expert is evaluated on every token and masked by `indices == i` (one dataset index per
+    image), the masked sum is concatenated behind the shared channels."""
     u = F.linear(x, sd[pre + 'fc1.weight'], sd[pre + 'fc1.bias'])
     h = F.gelu(u)
     if taps is not None:
         taps['fc1_pre'] = u
         taps['fc1_act'] = h
-    return F.linear(h, sd[pre + 'fc2.weight'], sd[pre + 'fc2.bias'])
+    shared = F.linear(h, sd[pre + 'fc2.weight'], sd[pre + 'fc2.bias'])
+    if pre + 'experts.0.weight' not in sd:
+        return shared
+    part = sd[pre + 'experts.0.weight'].shape[0]
+    expert_x = torch.zeros_like(x[:, :, -part:])
+    idx = indices.view(-1, 1, 1)
+    i = 0
+    while pre + f'experts.{i}.weight' in sd:
+        cur = F.linear(h, sd[pre + f'experts.{i}.weight'], sd[pre + f'experts.{i}.bias']) * (idx == i)
+        expert_x = expert_x + cur
+        i += 1
+    return torch.cat([shared, expert_x], dim=-1)
 
 
 def drop_path_rates(cfg: dict) -> List[float]:
@@ -122,7 +137,8 @@ def drop_path_scale(mask_u: Tensor, p: float) -> Tensor:
 
 
 def block(sd: Dict[str, Tensor], i: int, x: Tensor, cfg: dict,
-          dp: Optional[Tuple[Tensor, Tensor]] = None, taps: Optional[dict] = None) -> Tensor:
+          dp: Optional[Tuple[Tensor, Tensor]] = None, taps: Optional[dict] = None,
+          indices: Optional[Tensor] = None) -> Tensor:
     """vit.py:137-140: x += DropPath(attn(LN1(x))); x += DropPath(mlp(LN2(x))),
     LayerNorm eps = 1e-6 (vit.py:212).  `dp` = per-sample scale vectors [B] for
     the two DropPath sites (None = eval / rate 0)."""
@@ -134,7 +150,7 @@ def block(sd: Dict[str, Tensor], i: int, x: Tensor, cfg: dict,
         a = a * dp[0].view(-1, 1, 1)
     x = x + a
     xn2 = F.layer_norm(x, (E,), sd[pre + 'norm2.weight'], sd[pre + 'norm2.bias'], 1e-6)
-    m = mlp(sd, pre + 'mlp.', xn2, taps)
+    m = mlp(sd, pre + 'mlp.', xn2, taps, indices)
     if dp is not None:
         m = m * dp[1].view(-1, 1, 1)
     if taps is not None:
@@ -146,15 +162,16 @@ def block(sd: Dict[str, Tensor], i: int, x: Tensor, cfg: dict,
 
 def vit_forward(sd: Dict[str, Tensor], img: Tensor, cfg: dict,
                 dp_scales: Optional[Sequence[Tuple[Tensor, Tensor]]] = None,
-                return_tokens: bool = False) -> Tensor:
+                return_tokens: bool = False, dataset_source: Optional[Tensor] = None) -> Tensor:
     """vit.py:313-332: patch_embed -> + pos_embed[:,1:] + pos_embed[:,:1] -> blocks
-    -> last_norm -> permute(0,2,1).reshape(B,E,Hp,Wp)."""
+    -> last_norm -> permute(0,2,1).reshape(B,E,Hp,Wp).  ViTMoE (vit_moe.py:357-376) is the same
+    sequence with `dataset_source` handed to every Block's MoEMlp."""
     B = img.shape[0]
     x, (Hp, Wp) = patch_embed(sd, img, cfg)
     pe = sd['pos_embed']
     x = x + pe[:, 1:] + pe[:, :1]
     for i in range(cfg['depth']):
-        x = block(sd, i, x, cfg, None if dp_scales is None else dp_scales[i])
+        x = block(sd, i, x, cfg, None if dp_scales is None else dp_scales[i], indices=dataset_source)
     if cfg.get('last_norm', True):
         x = F.layer_norm(x, (x.shape[-1],), sd['last_norm.weight'], sd['last_norm.bias'], 1e-6)
     if return_tokens:
@@ -314,8 +331,12 @@ def vit_param_shapes(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
                 (b + 'attn.qkv.weight', (3 * E, E)), (b + 'attn.qkv.bias', (3 * E,)),
                 (b + 'attn.proj.weight', (E, E)), (b + 'attn.proj.bias', (E,)),
                 (b + 'norm2.weight', (E,)), (b + 'norm2.bias', (E,)),
-                (b + 'mlp.fc1.weight', (Hd, E)), (b + 'mlp.fc1.bias', (Hd,)),
-                (b + 'mlp.fc2.weight', (E, Hd)), (b + 'mlp.fc2.bias', (E,))]
+                (b + 'mlp.fc1.weight', (Hd, E)), (b + 'mlp.fc1.bias', (Hd,))]
+        part = cfg.get('part_features') or 0          # ViTMoE: vit_moe.py:86,92-96
+        out += [(b + 'mlp.fc2.weight', (E - part, Hd)), (b + 'mlp.fc2.bias', (E - part,))]
+        if part:
+            for j in range(cfg.get('num_expert', 1)):
+                out += [(b + f'mlp.experts.{j}.weight', (part, Hd)), (b + f'mlp.experts.{j}.bias', (part,))]
     if cfg.get('last_norm', True):
         out += [('last_norm.weight', (E,)), ('last_norm.bias', (E,))]
     return out
@@ -398,6 +419,23 @@ def split_state(sd: Dict[str, Tensor]) -> Tuple[Dict[str, Tensor], Dict[str, Ten
     bb = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}
     hd = {k[len('keypoint_head.'):]: v for k, v in sd.items() if k.startswith('keypoint_head.')}
     return bb, hd
+
+
+def topdown_moe_losses(bb: Dict[str, Tensor], heads: Sequence[Dict[str, Tensor]], img: Tensor, target: Tensor,
+                       tw: Tensor, dataset_source: Tensor, vcfg: dict, hcfgs: Sequence[dict], training: bool = True,
+                       dp_scales=None, use_target_weight: bool = True):
+    """models/detectors/top_down_moe.py:166-203 (forward_train): the routed backbone once, then every head on
+    every image with the targets / target weights of the other datasets' images zeroed.  Returns
+    (losses per head, heat maps per head)."""
+    feat = vit_forward(bb, img, vcfg, dp_scales, dataset_source=dataset_source)
+    losses, heats = [], []
+    for i, (hd, hcfg) in enumerate(zip(heads, hcfgs)):
+        sel = (dataset_source == i)
+        out = head_forward(hd, feat, hcfg, training)
+        losses.append(joints_mse_loss(out, target * sel.view(-1, 1, 1, 1), tw * sel.view(-1, 1, 1),
+                                      use_target_weight))
+        heats.append(out)
+    return losses, heats
 
 
 def topdown_forward(bb: Dict[str, Tensor], hd: Dict[str, Tensor], img: Tensor, vcfg: dict,

@@ -304,7 +304,70 @@ def pipeline():
     save('pipeline.npz', **out)
 
 
+MOE = dict(img_size=(256, 192), patch_size=16, in_chans=3, embed_dim=192, depth=3, num_heads=6, mlp_ratio=4,
+           qkv_bias=True, ratio=1, last_norm=True, drop_path_rate=0.0, num_expert=3, part_features=48)
+MOE_SOURCES = [0, 2, 1, 0, 2, 0]      # dataset index of each image of the fixture batch
+
+
+def vitpose_plus():
+    """ViTPose+ (ViTMoE + TopDownMoE): the reference detector class itself, built through the stub registry,
+    train-mode forward_train losses + gradients and the eval-mode main-head heat maps."""
+    refm = ref_loader.load_reference_moe()
+    vcfg = dict(MOE)
+    bb = O.synth_vit_weights(vcfg, seed=90)
+    hc = O.classic_head_cfg(vcfg['embed_dim'])
+    heads = [O.synth_head_weights(hc, seed=91 + j) for j in range(3)]
+
+    def hcfg():
+        return dict(type='TopdownHeatmapSimpleHead', in_channels=hc['in_channels'], out_channels=hc['out_channels'],
+                    num_deconv_layers=hc['num_deconv_layers'], num_deconv_filters=hc['num_deconv_filters'],
+                    num_deconv_kernels=hc['num_deconv_kernels'], extra=hc['extra'],
+                    loss_keypoint=dict(type='JointsMSELoss', use_target_weight=True))
+    det = refm.TopDownMoE(
+        backbone=dict(type='ViTMoE', img_size=vcfg['img_size'], patch_size=16, embed_dim=vcfg['embed_dim'],
+                      depth=vcfg['depth'], num_heads=vcfg['num_heads'], ratio=1, use_checkpoint=False, mlp_ratio=4,
+                      qkv_bias=True, drop_path_rate=0.0, num_expert=vcfg['num_expert'],
+                      part_features=vcfg['part_features']),
+        keypoint_head=hcfg(), associate_keypoint_head=[hcfg(), hcfg()], train_cfg=dict(),
+        test_cfg=dict(flip_test=False, post_process='default', shift_heatmap=False, modulate_kernel=11))
+    det.backbone.load_state_dict(bb, strict=True)
+    det.keypoint_head.load_state_dict(heads[0], strict=False)
+    for j in range(2):
+        det.associate_keypoint_heads[j].load_state_dict(heads[1 + j], strict=False)
+    img, target, tw = O.synth_batch(len(MOE_SOURCES), seed=95)
+    metas = [dict(dataset_idx=s) for s in MOE_SOURCES]
+    det.train()
+    losses = det.forward_train(img, target, tw, metas)
+    total = losses['main_stream_loss'] + losses['1_loss'] + losses['2_loss']
+    total.backward()
+    out = dict(loss=torch.stack([losses['main_stream_loss'], losses['1_loss'], losses['2_loss']]).detach(),
+               acc=np.array([losses['main_stream_acc'], losses['1_acc'], losses['2_acc']], np.float64),
+               sources=np.array(MOE_SOURCES))
+    named = dict(det.named_parameters())
+    for k in ['backbone.blocks.0.mlp.fc2.bias', 'backbone.blocks.2.mlp.fc2.bias', 'backbone.blocks.1.mlp.experts.0.bias',
+              'backbone.blocks.1.mlp.experts.1.bias', 'backbone.blocks.2.mlp.experts.2.bias',
+              'backbone.blocks.0.mlp.fc1.bias', 'backbone.pos_embed', 'keypoint_head.final_layer.bias',
+              'associate_keypoint_heads.0.final_layer.bias', 'associate_keypoint_heads.1.deconv_layers.1.weight']:
+        out['g.' + k] = named[k].grad
+    for k in ['backbone.blocks.0.mlp.fc2.weight', 'backbone.blocks.2.mlp.fc2.weight',
+              'backbone.blocks.0.mlp.experts.0.weight', 'backbone.blocks.1.mlp.experts.1.weight',
+              'backbone.blocks.2.mlp.experts.2.weight', 'backbone.blocks.1.mlp.fc1.weight',
+              'backbone.blocks.0.attn.qkv.weight', 'associate_keypoint_heads.1.final_layer.weight']:
+        out['gs.' + k] = named[k].grad.flatten(1)[::4, ::4]
+    det.eval()
+    with torch.no_grad():
+        src = torch.tensor(MOE_SOURCES)
+        feat = det.backbone(img, src)
+        out['feat_sub'] = feat[:, ::4]
+        out['heat_main_sub'] = det.keypoint_head(feat)[:, ::4]
+        out['heat_assoc1_sub'] = det.associate_keypoint_heads[1](feat)[:, ::4]
+    save('vitpose_plus.npz', **out)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['vitpose_plus']:
+        vitpose_plus()
+        sys.exit(0)
     toy_vit()
     vitpose_s_eval()
     vitpose_s_train()
@@ -312,3 +375,4 @@ if __name__ == '__main__':
     misc()
     decode()
     pipeline()
+    vitpose_plus()

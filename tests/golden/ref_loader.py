@@ -192,6 +192,38 @@ def load_reference():
     return ns
 
 
+def load_reference_moe():
+    """ViTPose+ classes: ViTMoE (vit_moe.py) and TopDownMoE (top_down_moe.py).  The detector file imports
+    mmcv's image / visualisation helpers and decorators at module level; they are stubbed (the decorators as
+    identities, the drawing helpers as functions that raise) because forward_train / forward_test never
+    reach them."""
+    ns = load_reference()
+    vm = _load('mmpose.models.backbones.vit_moe', 'mmpose/models/backbones/vit_moe.py')
+
+    def _ident_deco(*a, **k):
+        return lambda f: f
+
+    def _unavailable(*a, **k):
+        raise RuntimeError('drawing helpers are not available in the stub loader')
+    sys.modules['mmcv'].imread = _unavailable
+    _mod('mmcv.image').imwrite = _unavailable
+    _mod('mmcv.utils')
+    _mod('mmcv.utils.misc').deprecated_api_warning = _ident_deco
+    _mod('mmcv.visualization')
+    _mod('mmcv.visualization.image').imshow = _unavailable
+    if 'mmcv.runner' not in sys.modules:
+        _mod('mmcv.runner')
+    sys.modules['mmcv.runner'].auto_fp16 = _ident_deco
+    core = sys.modules['mmpose.core']
+    core.imshow_bboxes = core.imshow_keypoints = _unavailable
+    _mod('mmpose.models.detectors')
+    sys.modules['mmpose.models'].builder = sys.modules['mmpose.models.builder']
+    _load('mmpose.models.detectors.base', 'mmpose/models/detectors/base.py')
+    td = _load('mmpose.models.detectors.top_down_moe', 'mmpose/models/detectors/top_down_moe.py')
+    ns.ViTMoE, ns.TopDownMoE = vm.ViTMoE, td.TopDownMoE
+    return ns
+
+
 # Layer-decay parameter groups: the constructor file subclasses an mmcv class, so
 # only its pure function `get_num_layer_for_vit` is executed from source; the
 # group assembly loop is re-driven with the same arithmetic by make_golden.py.

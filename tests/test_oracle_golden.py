@@ -159,3 +159,45 @@ def test_layer_decay_groups(golden_dir):
         assert len(got) == len(ref)
         for pn, lid, scale, lr, wd in got:
             assert ref[pn] == pytest.approx([scale, lr, wd], rel=1e-12), pn
+
+
+MOE = dict(img_size=(256, 192), patch_size=16, in_chans=3, embed_dim=192, depth=3, num_heads=6, mlp_ratio=4,
+           qkv_bias=True, ratio=1, last_norm=True, drop_path_rate=0.0, num_expert=3, part_features=48)
+
+
+def test_vitpose_plus(golden_dir):
+    """ViTMoE + TopDownMoE: the oracle against the reference detector's own forward_train / backward
+    (vit_moe.py, top_down_moe.py executed from source by make_golden.py: vitpose_plus)."""
+    g = np.load(os.path.join(golden_dir, 'vitpose_plus.npz'))
+    src = torch.tensor(g['sources'])
+    bb = {k: v.requires_grad_() for k, v in O.synth_vit_weights(MOE, seed=90).items()}
+    hc = O.classic_head_cfg(MOE['embed_dim'])
+    heads = [{k: (v.requires_grad_() if 'running' not in k else v) for k, v in O.synth_head_weights(hc, seed=91 + j).items()}
+             for j in range(3)]
+    img, target, tw = O.synth_batch(len(src), seed=95)
+    losses, _ = O.topdown_moe_losses(bb, heads, img, target, tw, src, MOE, [hc] * 3, training=True)
+    close(torch.stack(losses), g['loss'], 1e-5, 1e-7)
+    sum(losses).backward()
+    prefixes = {'backbone.': bb, 'keypoint_head.': heads[0], 'associate_keypoint_heads.0.': heads[1],
+                'associate_keypoint_heads.1.': heads[2]}
+    checked = 0
+    for k in g.files:
+        if not (k.startswith('g.') or k.startswith('gs.')):
+            continue
+        name = k.split('.', 1)[1]
+        pre = next(p for p in prefixes if name.startswith(p))
+        grad = prefixes[pre][name[len(pre):]].grad
+        if k.startswith('gs.'):
+            grad = grad.flatten(1)[::4, ::4]
+        close(grad, g[k], 2e-4, 1e-7)
+        checked += 1
+    assert checked == 18
+    # an expert only receives gradient from its own dataset's images: expert 1 of block 1 is non-zero here
+    assert np.abs(g['gs.backbone.blocks.1.mlp.experts.1.weight']).max() > 0
+    with torch.no_grad():
+        # eval mode after one training pass: the BatchNorm running statistics carry that pass's update
+        heads_e = [{k: v.detach() for k, v in h.items()} for h in heads]
+        feat = O.vit_forward({k: v.detach() for k, v in bb.items()}, img, MOE, dataset_source=src)
+        close(feat[:, ::4], g['feat_sub'], 1e-4, 1e-4)
+        close(O.head_forward(heads_e[0], feat, hc)[:, ::4], g['heat_main_sub'], 1e-4, 1e-4)
+        close(O.head_forward(heads_e[2], feat, hc)[:, ::4], g['heat_assoc1_sub'], 1e-4, 1e-4)

@@ -32,6 +32,7 @@ class GemmArgs(Structure):
         ('split_k', c_int), ('split_stride', c_long),
         ('out_row_div', c_int), ('out_row_hi', c_int), ('out_row_lo', c_int), ('out_row_off', c_int),
         ('tail_ws', c_void_p), ('tail_ws_bytes', c_size_t), ('tail_force', c_int), ('tile_mode', c_int),
+        ('route_expert', c_void_p), ('route_delta', c_void_p), ('route_bias_delta', c_void_p), ('route_split', c_int),
     ]
 
 
@@ -40,7 +41,8 @@ P = c_void_p
 class GroupEntry(Structure):
     _fields_ = [('x', c_void_p), ('y', c_void_p), ('out', c_void_p),
                 ('ldx', c_int), ('ldy', c_int), ('ldo', c_int), ('M', c_int), ('N', c_int),
-                ('tiles_n', c_int), ('ntiles', c_int), ('tile0', c_int), ('rowsum', c_void_p)]
+                ('tiles_n', c_int), ('ntiles', c_int), ('tile0', c_int), ('rowsum', c_void_p),
+                ('kmap', c_void_p), ('nk_dev', c_void_p)]
 
 
 SIGNATURES = {
@@ -49,6 +51,7 @@ SIGNATURES = {
     'vp_deconv_weight_prep': [P, P, P, c_int, c_int, P],
     'vp_wgrad_group_table': [POINTER(GroupEntry), c_int, c_int, POINTER(c_int)],
     'vp_wgrad_grouped_bf16': [P, c_int, c_int, c_int, c_int, P],
+    'vp_wgrad_grouped_kmap_bf16': [P, c_int, c_int, c_int, P],
     'vp_splitk_reduce': [P, c_int, c_long, c_size_t, P, c_int, P],
     'vp_layernorm_fwd': [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, c_size_t, P],

@@ -24,6 +24,8 @@ class Registry:
         return self._module_dict
 
     def get(self, key):
+        if key not in self._module_dict:
+            from . import models  # noqa: F401  (registers the HIP-backed classes on first use)
         return self._module_dict.get(key)
 
     def __contains__(self, key):

@@ -50,11 +50,22 @@ def adapt_backbone_state_dict(model, state_dict, patch_padding='pad'):
     return sd
 
 
+def split_expert_state_dict(model, state_dict, part_features):
+    """mmcv_custom/checkpoint.py:396-404: a plain-ViT state dict enters a ViTMoE model by cutting every fc2
+    tensor into its first rows (the shared fc2) and its last `part_features` rows (copied into every expert)."""
+    import re
+    new = OrderedDict(state_dict)
+    for key in model.state_dict().keys():
+        if 'mlp.experts' in key:
+            new[key] = state_dict[re.sub(r'experts.\d+.', 'fc2.', key)][-part_features:]
+        elif 'fc2' in key:
+            new[key] = state_dict[key][:-part_features]
+    return new
+
+
 def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None, patch_padding='pad',
                     part_features=None):
     """Load a local checkpoint file into `model` (a ViT backbone or a whole TopDown)."""
-    if part_features is not None:
-        raise NotImplementedError('part_features (ViTPose+ expert split) is outside this path')
     checkpoint = torch.load(filename, map_location=map_location, weights_only=True)
     sd = _state_dict_of(checkpoint, filename)
     if list(sd.keys())[0].startswith('module.'):
@@ -63,6 +74,8 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=No
         sd = {k.replace('encoder.', ''): v for k, v in sd.items() if k.startswith('encoder.')}
     if hasattr(model, 'patch_embed'):
         sd = adapt_backbone_state_dict(model, sd, patch_padding)
+    if part_features is not None:
+        sd = split_expert_state_dict(model, sd, part_features)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     msgs = []
     if unexpected:

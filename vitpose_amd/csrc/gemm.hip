@@ -644,9 +644,11 @@ __device__ __forceinline__ void stage_half(const Operand& op, int r0, int k0, ch
 // work id -> problem by a ballot over the table's first-tile column (<= 64 problems), then the problem's
 // operands replace the kernel arguments (wave-uniform: read through the scalar path).
 __device__ __forceinline__ float* select_problem(const vp_group_entry* grp, int ngrp, int lane, int& work, Operand& X,
-                                                 Operand& Y, int& M, int& N, int& tiles_n, int& ntiles, Epi& e) {
+                                                 Operand& Y, int& M, int& N, int& tiles_n, int& ntiles, Epi& e,
+                                                 int* pidx = nullptr) {
     const int first = lane < ngrp ? grp[lane].tile0 : 0x7fffffff;
     const int p = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= work)) - 1);
+    if (pidx) *pidx = p;
     const vp_group_entry g = grp[p];
     X = Operand{(const bf16*)g.x, g.ldx, g.M};
     Y = Operand{(const bf16*)g.y, g.ldy, g.N};
@@ -900,6 +902,39 @@ __device__ __forceinline__ void stage_unit(const Operand& op, int r0, int k0, ch
                                      (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
 }
 
+// Per-image operand routing (mixture-of-experts FFN): the Y rows (k-contiguous Y: output columns; k-major Y:
+// reduction rows) at or beyond `split` come from the expert of the image the row tile belongs to, `delta`
+// elements further on in memory.
+struct Route {
+    const int* expert;        // [M / rows_per_image] expert index of every image; nullptr = no routing
+    const long* delta;        // [experts] element offset of expert e's rows relative to the shared matrix
+    const long* bias_delta;   // [experts] the same for the bias vector (or nullptr)
+    int split;
+};
+
+template <bool KMAJ>
+__device__ __forceinline__ void stage_unit_routed(const Operand& op, int r0, int k0, char* lds, int wave, int lane,
+                                                  int split, long delta) {
+    const int base = wave * 64;
+    const int L = base + lane;
+    const bf16* src;
+    if constexpr (!KMAJ) {
+        const int r = L >> 3, c = (L & 7) ^ (r & 7);
+        int row = r0 + r;
+        row = row < op.rows ? row : op.rows - 1;
+        src = op.p + (size_t)row * op.ld + k0 + c * 8 + (row >= split ? delta : 0);
+    } else {
+        const int kr = L >> 3, s16 = L & 7;
+        const int unit = (s16 >> 1) ^ kmaj64_key(kr);
+        int col = r0 + (unit * 2 + (s16 & 1)) * 8;
+        col = col <= op.rows - 8 ? col : op.rows - 8;
+        const int kk = k0 + kr;
+        src = op.p + (size_t)kk * op.ld + col + (kk >= split ? delta : 0);
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
+}
+
 // fragment `f` (16 rows / columns) of a 192-wide operand tile made of three 64-wide units
 template <bool KMAJ>
 __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s, int lane) {
@@ -916,10 +951,14 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s,
     }
 }
 
-template <bool XKMAJ, bool YKMAJ, int EPI>
+// ROUTE: per-image Y routing (see Route; a row tile is exactly one image of 192 tokens).
+// KMAP (grouped weight gradients only): a problem may reduce over a LIST of 64-token K tiles, kmap[t] = first
+// token row of its t-th tile, *nk_dev = their count (0 = the output is written as zeros).
+template <bool XKMAJ, bool YKMAJ, int EPI, bool ROUTE = false, bool KMAP = false>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Operand Y, int M, int N, int K,
                                                                 int tiles_n, int ntiles, int ksplit_tiles, Epi e,
-                                                                const vp_group_entry* gtab, int ngtab) {
+                                                                const vp_group_entry* gtab, int ngtab,
+                                                                Route rt = Route{nullptr, nullptr, nullptr, 0}) {
     __shared__ __attribute__((aligned(16))) char lds[3][STAGE3_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -929,8 +968,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     // block of neighbouring tiles of ONE K slice, which walk the same operand panels in step (L2 reuse)
     int work = xcd_remap(blockIdx.x, gridDim.x);
     float* rowsum = nullptr;
+    int pidx = 0;
     if constexpr (XKMAJ && YKMAJ && EPI == VP_EPI_F32) {
-        if (gtab) rowsum = select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
+        if (gtab) rowsum = select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e, &pidx);
     }
     const int slice = work / ntiles;
     const int t = work - slice * ntiles;
@@ -941,7 +981,20 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     const int nk_all = K / BK;
     const int kt0 = slice * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
-    const int nk = kt1 - kt0;
+    int nk = kt1 - kt0;
+    const int* kmap = nullptr;
+    if constexpr (KMAP) {
+        if (gtab && gtab[pidx].kmap) {
+            kmap = gtab[pidx].kmap;
+            nk = min(*gtab[pidx].nk_dev, nk_all);
+        }
+    }
+    long ydelta = 0;
+    if constexpr (ROUTE) {
+        const int ex = rt.expert[i0 / T3];
+        ydelta = rt.delta[ex];
+        if (e.bias && rt.bias_delta && j0 + wc * 48 >= rt.split) e.bias += rt.bias_delta[ex];
+    }
 
     f32x4 acc[6][3];
 #pragma unroll
@@ -961,9 +1014,14 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         constexpr bool RS = decltype(rs_tag)::value;
         // unit 0-2 = X rows 0-63 / 64-127 / 128-191, 3-5 = Y columns likewise; K tile u lives in stage u % 3
         auto stage = [&](int unit, int u, int st) {
-            const int k0 = (kt0 + (u < nk ? u : nk - 1)) * BK;
+            const int kt = kt0 + (u < nk ? u : nk - 1);
+            int k0 = kt * BK;
+            if constexpr (KMAP) {
+                if (kmap) k0 = kmap[kt];
+            }
             char* dst = lds[st] + unit * UNIT_BYTES;
             if (unit < 3) stage_unit<XKMAJ>(X, i0 + unit * 64, k0, dst, wave, lane);
+            else if constexpr (ROUTE) stage_unit_routed<YKMAJ>(Y, j0 + (unit - 3) * 64, k0, dst, wave, lane, rt.split, ydelta);
             else stage_unit<YKMAJ>(Y, j0 + (unit - 3) * 64, k0, dst, wave, lane);
         };
 #pragma unroll
@@ -1148,6 +1206,29 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
         }
         VP_LAUNCH_RET();
     }
+    if (a->route_expert) {
+        // per-image expert routing: 192-row tiles (one image each), forward / data-gradient products
+        if (XK || split > 1 || a->M % T3 != 0 || a->route_split % 48 != 0 || !a->route_delta) return VP_ERR_UNSUPPORTED;
+        const int tn3 = (a->N + T3 - 1) / T3, nt3 = (a->M / T3) * tn3;
+        const Route rt{a->route_expert, a->route_delta, a->route_bias_delta, a->route_split};
+        if constexpr (!XK) {
+#define VP_GEMMR_CASE(EPI)                                                                                       \
+    case EPI:                                                                                                    \
+        hipLaunchKernelGGL((gemm192_kernel<false, YK, EPI, true>), dim3(nt3), dim3(T2_THREADS), 0, st, X, Y,    \
+                           a->M, a->N, a->K, tn3, nt3, ksplit_tiles, e, nullptr, 0, rt);                         \
+        break;
+            switch (a->epilogue) {
+                VP_GEMMR_CASE(VP_EPI_RESID_F32)
+                VP_GEMMR_CASE(VP_EPI_F32)
+                VP_GEMMR_CASE(VP_EPI_DGELU)
+                VP_GEMMR_CASE(VP_EPI_BF16)
+                default:
+                    return VP_ERR_UNSUPPORTED;
+            }
+#undef VP_GEMMR_CASE
+        }
+        VP_LAUNCH_RET();
+    }
     if (a->tile_mode == 3) {
         const int tm3 = (a->M + T3 - 1) / T3, tn3 = (a->N + T3 - 1) / T3, nt3 = tm3 * tn3;
         dim3 grid3(nt3 * split);
@@ -1237,6 +1318,7 @@ extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
     if (a->out2) VP_CHECK_ARG(((uintptr_t)a->out2 & 15) == 0);
     if (a->rowscale) VP_CHECK_ARG(a->rows_per_scale > 0);
     if (a->pos) VP_CHECK_ARG(a->pos_rows > 0);
+    if (a->route_expert) VP_CHECK_ARG(a->route_delta && a->route_split >= 0 && !a->x_kmajor);
     if (a->x_kmajor) return a->y_kmajor ? launch_layout<true, true>(a, stream) : launch_layout<true, false>(a, stream);
     return a->y_kmajor ? launch_layout<false, true>(a, stream) : launch_layout<false, false>(a, stream);
 }
@@ -1274,6 +1356,18 @@ extern "C" int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count,
     else
         hipLaunchKernelGGL((gemm192_kernel<true, true, VP_EPI_F32>), dim3(total_tiles), dim3(T2_THREADS), 0, stream,
                            none, none, 0, 0, K, 1, 1, K / BK, e, table_dev, count);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_wgrad_grouped_kmap_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K,
+                                          hipStream_t stream) {
+    VP_CHECK_ARG(table_dev && count > 0 && count <= 64 && total_tiles > 0 && K > 0 && K % BK == 0);
+    Operand none{nullptr, 0, 0};
+    Epi e{};
+    e.kind = VP_EPI_F32;
+    hipLaunchKernelGGL((gemm192_kernel<true, true, VP_EPI_F32, false, true>), dim3(total_tiles), dim3(T2_THREADS), 0,
+                       stream, none, none, 0, 0, K, 1, 1, K / BK, e, table_dev, count,
+                       Route{nullptr, nullptr, nullptr, 0});
     VP_LAUNCH_RET();
 }
 

@@ -134,8 +134,12 @@ def _slab_elems(out_elems, K, target_blocks=None):
 # ViT backbone
 # =====================================================================================
 def vit_param_shapes(cfg) -> List[Tuple[str, Tuple[int, ...]]]:
-    """State-dict keys/shapes of the backbone (identical to the reference ViT's)."""
+    """State-dict keys/shapes of the backbone (identical to the reference ViT's; with `part_features`
+    those of ViTMoE, vit_moe.py:78-96: fc2 keeps E - part_features outputs, every expert adds a
+    Linear(hidden, part_features))."""
     E = cfg['embed_dim']
+    P = cfg.get('part_features') or 0
+    nexp = cfg.get('num_expert', 1) if P else 0
     Hd = int(E * cfg.get('mlp_ratio', 4))
     p = cfg['patch_size']
     H, W = cfg['img_size']
@@ -153,7 +157,9 @@ def vit_param_shapes(cfg) -> List[Tuple[str, Tuple[int, ...]]]:
         out += [(b + 'attn.proj.weight', (E, E)), (b + 'attn.proj.bias', (E,)),
                 (b + 'norm2.weight', (E,)), (b + 'norm2.bias', (E,)),
                 (b + 'mlp.fc1.weight', (Hd, E)), (b + 'mlp.fc1.bias', (Hd,)),
-                (b + 'mlp.fc2.weight', (E, Hd)), (b + 'mlp.fc2.bias', (E,))]
+                (b + 'mlp.fc2.weight', (E - P, Hd)), (b + 'mlp.fc2.bias', (E - P,))]
+        for j in range(nexp):
+            out += [(b + f'mlp.experts.{j}.weight', (P, Hd)), (b + f'mlp.experts.{j}.bias', (P,))]
     if cfg.get('last_norm', True):
         out += [('last_norm.weight', (E,)), ('last_norm.bias', (E,))]
     return out
@@ -193,6 +199,58 @@ class VitRunner:
         self.dpos = torch.empty(self.T, self.E, dtype=torch.float32, device=dev)
         rates = torch.linspace(0, cfg.get('drop_path_rate', 0.), self.depth)
         self.dp_rates = [r.item() for r in rates]
+        # mixture-of-experts FFN (ViTMoE): the last `part` output channels of fc2 come from the expert Linear of
+        # the image's dataset.  The GEMM kernels read the expert's rows `delta` elements beyond where the shared
+        # matrix would hold them (offsets inside the flat parameter buffers, identical for f32 / bf16 / gradients).
+        self.part = cfg.get('part_features') or 0
+        self.nexp = cfg.get('num_expert', 1) if self.part else 0
+        self.moe_delta, self.moe_bdelta = [], []
+        if self.part:
+            if self.T != 192:
+                raise NotImplementedError('expert routing needs 192 tokens per image (one GEMM row tile each)')
+            Ns, off = self.E - self.part, store.offsets
+            if Ns % 48 or self.part % 8:
+                raise NotImplementedError('embed_dim - part_features must be a multiple of 48')
+            for i in range(self.depth):
+                b = f'{prefix}blocks.{i}.mlp.'
+                self.moe_delta.append(torch.tensor(
+                    [off[b + f'experts.{j}.weight'] - off[b + 'fc2.weight'] - Ns * self.hidden
+                     for j in range(self.nexp)], dtype=torch.int64, device=dev))
+                self.moe_bdelta.append(torch.tensor(
+                    [off[b + f'experts.{j}.bias'] - off[b + 'fc2.bias'] - Ns for j in range(self.nexp)],
+                    dtype=torch.int64, device=dev))
+
+    def route_buffers(self, ws: 'Workspace', B: int):
+        """Plan-owned routing state of one batch size: expert [B] (the images' dataset indices) and, for the
+        expert weight gradients, per expert the list of 64-token K tiles of its images (kmap) and their count."""
+        return (ws.get(f'moe_expert.{B}', (B,), torch.int32, zero=True),
+                ws.get(f'moe_kmap.{B}', (max(self.nexp, 1), 3 * B), torch.int32, zero=True),
+                ws.get(f'moe_nk.{B}', (max(self.nexp, 1),), torch.int32, zero=True))
+
+    def set_routing(self, ws: 'Workspace', B: int, dataset_source):
+        """Fill the routing buffers from the per-image dataset indices (host list / array / tensor)."""
+        import numpy as np
+        src = dataset_source.detach().cpu().numpy() if isinstance(dataset_source, torch.Tensor) else np.asarray(dataset_source)
+        src = src.astype(np.int64).reshape(-1)
+        if src.shape[0] != B:
+            raise ValueError(f'{src.shape[0]} dataset indices for a batch of {B} images')
+        if src.min() < 0 or src.max() >= self.nexp:
+            raise ValueError(f'dataset index outside [0, {self.nexp}) (num_expert)')
+        expert, kmap, nk = self.route_buffers(ws, B)
+        km = np.zeros((self.nexp, 3 * B), np.int32)
+        cnt = np.zeros(self.nexp, np.int32)
+        for b, e in enumerate(src):
+            km[e, cnt[e]:cnt[e] + 3] = b * self.T + np.arange(3) * 64
+            cnt[e] += 3
+        expert.copy_(torch.from_numpy(src.astype(np.int32)))
+        kmap.copy_(torch.from_numpy(km))
+        nk.copy_(torch.from_numpy(cnt))
+
+    def _route(self, ws, B, i, with_bias=True):
+        if not self.part:
+            return None
+        expert = self.route_buffers(ws, B)[0]
+        return (expert, self.moe_delta[i], self.moe_bdelta[i] if with_bias else None, self.E - self.part)
 
     # -- names --
     def w(self, n):
@@ -262,7 +320,7 @@ class VitRunner:
             xo = ws.f32(f'x_in.{i + 1}' if training else 'x_a', M, E)
             plan.gemm(hact, self.h(b + 'mlp.fc2.weight'), xo, M, E, Hd, ldx=Hd, ldy=Hd, ldo=E,
                       epilogue=_lib.VP_EPI_RESID_F32, bias=self.w(b + 'mlp.fc2.bias'), resid=xm,
-                      rowscale=dp[i, 1] if use_dp else None, rows_per_scale=T)
+                      rowscale=dp[i, 1] if use_dp else None, rows_per_scale=T, route=self._route(ws, B, i))
             x = xo
         feat = ws.bf16('feat', M, E)
         if self.cfg.get('last_norm', True):
@@ -319,7 +377,7 @@ class VitRunner:
                        ldx=E, ldy=E, ldo=Hd, bias=self.w(b + 'mlp.fc1.bias'))
             plan.finish_f32(acc, M, Hd, ldx=Hd, ldo=Hd, hi=hh, lo=hl, act=1)
             plan.gemm3(hh, hl, self.h(b + 'mlp.fc2.weight'), wl(b + 'mlp.fc2.weight'), acc, M, E, Hd,
-                       ldx=Hd, ldy=Hd, ldo=E, bias=self.w(b + 'mlp.fc2.bias'))
+                       ldx=Hd, ldy=Hd, ldo=E, bias=self.w(b + 'mlp.fc2.bias'), route=self._route(ws, B, i))
             plan.finish_f32(acc, M, E, ldx=E, ldo=E, out=x, resid=xm, ldr=E)
         feat = ws.f32('x_feat', M, E)
         if self.cfg.get('last_norm', True):
@@ -359,8 +417,26 @@ class VitRunner:
         # launch per `group_blocks` Blocks: 4 Blocks of ViTPose-B are 768 tiles of 192 x 192 = 3 whole
         # rounds of the chip, no slices, no slabs.
         G = group_blocks if group_blocks is not None else WGRAD_GROUP_BLOCKS
+        P, Ns = self.part, self.E - self.part
+        if P:
+            G = max(G, 1)     # the expert weight gradients exist in the grouped launch only
+            _, kmap, nk_dev = self.route_buffers(ws, B)
+            colsum_scratch = ws.f32('moe_colsum_scratch', E)
         slab = ws.f32('splitk_slab', _slab_elems(max(E * Hd, 3 * E * E, E * self.Kpe), M)) if G <= 0 else None
         pending = []
+
+        def defer_fc2(dxb_t, h_t, b):
+            """fc2 of a mixture-of-experts FFN: the shared rows reduce over every token, expert j's rows over the
+            tokens of its images; the bias gradients are the row sums of the same problems."""
+            pending.append((dxb_t, h_t, self.g(b + 'mlp.fc2.weight'), Ns, Hd, E, Hd, self.g(b + 'mlp.fc2.bias')))
+            xe = dxb_t.view(-1)[Ns:]
+            for j in range(self.nexp):
+                pending.append((xe, h_t, self.g(b + f'mlp.experts.{j}.weight'), P, Hd, E, Hd,
+                                self.g(b + f'mlp.experts.{j}.bias'), kmap[j], nk_dev[j:j + 1]))
+
+        def fc2_bias_grad(i):
+            """Target of the LayerNorm-backward column sums of the gradient that enters Block i's fc2."""
+            return colsum_scratch if P else self.g(f'blocks.{i}.mlp.fc2.bias')
 
         def defer(x, y, name, Mw, Nw, bias=None):
             """Weight gradient x^T y (and, with `bias`, that Linear's bias gradient = column sums of x)."""
@@ -384,7 +460,7 @@ class VitRunner:
         if self.cfg.get('last_norm', True):
             plan.layernorm_bwd(dfeat, x_last, ws.bufs['mean_l'], ws.bufs['rstd_l'], self.w('last_norm.weight'),
                                None, dx_a, dxb, dp_scale(last, 1), T, self.g('last_norm.weight'),
-                               self.g('last_norm.bias'), self.g(f'blocks.{last}.mlp.fc2.bias'), M, E, workspace=lnws)
+                               self.g('last_norm.bias'), fc2_bias_grad(last), M, E, workspace=lnws)
         else:
             raise NotImplementedError('last_norm=False backward')
         dx = dx_a
@@ -398,11 +474,14 @@ class VitRunner:
             # ---- MLP branch: x_out = x_mid + s * (fc2(gelu(fc1(LN2(x_mid)))))
             # du = (dxb W2) * gelu'(u)
             plan.gemm(dxb, self.h(b + 'mlp.fc2.weight'), du, M, Hd, E, ldx=E, ldy=Hd, ldo=Hd, y_kmajor=True,
-                      epilogue=_lib.VP_EPI_DGELU, aux=g['u' + s], ldaux=Hd)
+                      epilogue=_lib.VP_EPI_DGELU, aux=g['u' + s], ldaux=Hd, route=self._route(ws, B, i, False))
             plan.fork()
             with plan.on_side():
                 # dW2 [E][Hd] = dxb^T h ; dW1 [Hd][E] = du^T xn2 ; db1 = colsum(du)
-                defer(dxb, g['h' + s], b + 'mlp.fc2.weight', E, Hd)
+                if P:
+                    defer_fc2(dxb, g['h' + s], b)
+                else:
+                    defer(dxb, g['h' + s], b + 'mlp.fc2.weight', E, Hd)
                 defer(du, g['xn2' + s], b + 'mlp.fc1.weight', Hd, E, bias=b + 'mlp.fc1.bias')
             # dxn2 = du W1
             plan.gemm(du, self.h(b + 'mlp.fc1.weight'), dxn, M, E, Hd, ldx=Hd, ldy=E, ldo=E, y_kmajor=True)
@@ -424,7 +503,7 @@ class VitRunner:
             plan.gemm(dqkv, self.h(b + 'attn.qkv.weight'), dxn, M, E, 3 * E, ldx=3 * E, ldy=E, ldo=E, y_kmajor=True)
             # LN1 backward: bf16 copy is scaled for the previous block's MLP branch (or unscaled for
             # the patch embedding), its column sum is that branch's fc2 bias (or the patch bias) grad
-            nxt_bias = self.g(f'blocks.{i - 1}.mlp.fc2.bias') if i > 0 else self.g('patch_embed.proj.bias')
+            nxt_bias = fc2_bias_grad(i - 1) if i > 0 else self.g('patch_embed.proj.bias')
             dxb = dxb_buf(f'{i - 1}.mlp' if i > 0 else 'patch')
             plan.layernorm_bwd(dxn, g['x_in' + s], g['mean1' + s], g['rstd1' + s], self.w(b + 'norm1.weight'),
                                dx, other, dxb, dp_scale(i - 1, 1), T, self.g(b + 'norm1.weight'),

@@ -328,6 +328,9 @@ class ViT(_FlatBound):
         self._refresh()
         fwd, _, io = self._plan(B, keep)
         io['img'].copy_(img)
+        if vr.part:
+            src = self._dataset_source
+            vr.set_routing(self._runners[('ws', keep)], B, src if src is not None else [0] * B)
         if keep:
             if self.training and max(vr.dp_rates) > 0:
                 vr.sample_drop_path(io['dp'])
@@ -352,8 +355,72 @@ class ViT(_FlatBound):
             return _ViTFunction.apply(self, x.float(), *params)
         return self._run(x.float(), keep=False)
 
+    _dataset_source = None
+
     def forward(self, x):
         return self.forward_features(x)
+
+
+class MoEMlp(_Holder):
+    """vit_moe.py:78-115: fc2 emits the shared out - part_features channels, expert `indices[b]` (a
+    Linear(hidden, part_features)) the rest of image b."""
+
+    def __init__(self, num_expert=1, in_features=1024, hidden_features=None, out_features=None, drop=0.,
+                 part_features=256):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.part_features = part_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, out_features - part_features)
+        self.drop = nn.Dropout(drop)
+        self.num_expert = num_expert
+        self.experts = nn.ModuleList([nn.Linear(hidden_features, part_features) for _ in range(num_expert)])
+
+
+@BACKBONES.register_module()
+class ViTMoE(ViT):
+    """ViTPose+ backbone (vit_moe.py:241-385): a ViT whose FFNs route the last `part_features` channels through
+    one of `num_expert` expert Linears chosen per image by `dataset_source`.  The reference evaluates every
+    expert on every token and masks (vit_moe.py:107-111); here the GEMM reads the image's expert rows directly."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=80, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., hybrid_backbone=None, norm_layer=None, use_checkpoint=False,
+                 frozen_stages=-1, ratio=1, last_norm=True, patch_padding='pad', freeze_attn=False,
+                 freeze_ffn=False, num_expert=1, part_features=None):
+        super().__init__(img_size, patch_size, in_chans, num_classes, embed_dim, depth, num_heads, mlp_ratio,
+                         qkv_bias, qk_scale, drop_rate, attn_drop_rate, drop_path_rate, hybrid_backbone, norm_layer,
+                         use_checkpoint, frozen_stages, ratio, last_norm, patch_padding, freeze_attn, freeze_ffn)
+        if not part_features:
+            raise TypeError('ViTMoE needs part_features (vit_moe.py:86 subtracts it from the fc2 width)')
+        self.part_features = part_features
+        for blk in self.blocks:
+            blk.mlp = MoEMlp(num_expert, embed_dim, int(embed_dim * mlp_ratio), drop=drop_rate,
+                             part_features=part_features)
+        self._cfg.update(num_expert=num_expert, part_features=part_features)
+        self._freeze_stages()
+
+    def init_weights(self, pretrained=None):
+        """vit_moe.py:330-348; a checkpoint's fc2 rows are split into the shared part and (copied to every
+        expert) the last part_features rows (mmcv_custom/checkpoint.py:396-404)."""
+        if isinstance(pretrained, str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False, patch_padding=self.patch_padding,
+                            part_features=self.part_features)
+        else:
+            super().init_weights(pretrained)
+
+    def forward_features(self, x, dataset_source=None):
+        self._dataset_source = dataset_source
+        try:
+            return super().forward_features(x)
+        finally:
+            self._dataset_source = None
+
+    def forward(self, x, dataset_source=None):
+        return self.forward_features(x, dataset_source)
 
 
 # =====================================================================================
@@ -1014,6 +1081,7 @@ class TopDown(nn.Module):
         self.fp16_enabled = False
         self.backbone = build_backbone(backbone)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self._src = None
         if neck is not None:
             self.neck = build_neck(neck)
         if keypoint_head is not None:
@@ -1043,14 +1111,29 @@ class TopDown(nn.Module):
             self.keypoint_head.init_weights()
 
     # ---- fused storage / plan ----
+    def _heads(self):
+        """(state-dict prefix, head) of every head: the main one, then TopDownMoE's associate heads."""
+        out = [('keypoint_head.', self.keypoint_head)] if self.with_keypoint else []
+        return out + [(f'associate_keypoint_heads.{j}.', h)
+                      for j, h in enumerate(getattr(self, 'associate_keypoint_heads', []))]
+
+    def _src_of(self, img_metas):
+        """Per-image dataset indices (TopDownMoE only)."""
+        return None
+
+    def _backbone(self, img, img_metas=None):
+        return self.backbone(img)
+
     def _fusable(self):
         return (isinstance(self.backbone, ViT) and not self.with_neck and self.with_keypoint and
-                isinstance(self.keypoint_head, TopdownHeatmapSimpleHead) and
-                isinstance(self.keypoint_head.loss, JointsMSELoss))
+                all(isinstance(h, TopdownHeatmapSimpleHead) and isinstance(h.loss, JointsMSELoss)
+                    for _, h in self._heads()))
 
     def _apply(self, fn, *a, **k):
         if self._fusable():
-            self.backbone._owned = self.keypoint_head._owned = True
+            self.backbone._owned = True
+            for _, h in self._heads():
+                h._owned = True
         out = super()._apply(fn, *a, **k)
         if self._fusable():
             self._bind()
@@ -1060,21 +1143,26 @@ class TopDown(nn.Module):
         from .pose_engine import PoseEngine
         self._engine = None
         bb, hd = self.backbone, self.keypoint_head
-        for m in (bb, hd):
+        heads = self._heads()
+        mods = [bb] + [h for _, h in heads]
+        for m in mods:
             m._store, m._runners, m._plans = None, {}, {}
+            m._prefix = ''
         dev = bb.pos_embed.device
-        bb._prefix = hd._prefix = ''
         if dev.type != 'cuda':
-            bb._owned = hd._owned = False
+            for m in mods:
+                m._owned = False
             return
         try:
             eng = PoseEngine(bb._cfg, hd._cfg, dev, loss_weight=hd.loss.loss_weight,
-                             use_target_weight=hd.loss.use_target_weight)
+                             use_target_weight=hd.loss.use_target_weight,
+                             assoc_heads=[(h._cfg, h.loss.loss_weight, h.loss.use_target_weight)
+                                          for _, h in heads[1:]])
         except NotImplementedError:
             # a shape outside the fused plan's kernels: fall back to module-by-module HIP execution
-            bb._owned = hd._owned = False
-            bb._bind()
-            hd._bind()
+            for m in mods:
+                m._owned = False
+                m._bind()
             return
         st = eng.store
         for n, p in self.named_parameters():
@@ -1086,9 +1174,8 @@ class TopDown(nn.Module):
                 eng.buffers[n].copy_(b.data)
                 b.data = eng.buffers[n]
         # the sub-modules run from the same store when called on their own
-        bb._store = hd._store = st
-        bb._prefix, hd._prefix = 'backbone.', 'keypoint_head.'
-        bb._seen_version = hd._seen_version = None
+        for pre, m in [('backbone.', bb)] + heads:
+            m._store, m._prefix, m._seen_version = st, pre, None
         self._grad_views = [(p, st.gview(n)) for n, p in self.named_parameters()]
         self._engine = eng
         self._seen_version = None
@@ -1104,9 +1191,7 @@ class TopDown(nn.Module):
         B = img.shape[0]
         self._refresh()
         plan, io = eng._train_plan(B)
-        io['img'].copy_(img)
-        io['target'].copy_(target)
-        io['tw'].copy_(tw.reshape(B, -1))
+        eng.load_batch(io, img, target, tw, self._src)
         vr = eng.vit
         if self.backbone.training and max(vr.dp_rates) > 0:
             vr.sample_drop_path(io['dp'])
@@ -1114,11 +1199,14 @@ class TopDown(nn.Module):
             io['dp'].fill_(1.0)
         self._stash = self._stash_live()
         plan.run(first=0, last=eng.n_fwd_calls)
-        if self.keypoint_head.training:
-            for m in self.keypoint_head.modules():
-                if isinstance(m, nn.BatchNorm2d):
-                    m.num_batches_tracked += 1
-        self._heat = io['heat']
+        for _, h in self._heads():
+            if h.training:
+                for m in h.modules():
+                    if isinstance(m, nn.BatchNorm2d):
+                        m.num_batches_tracked += 1
+        self._heat, self._heats = io['heat'], io['heats']
+        if len(io['losses']) > 1:
+            return torch.cat(io['losses'])       # one loss per head
         return io['loss'].reshape(()).clone()
 
     def _stash_live(self):
@@ -1132,7 +1220,8 @@ class TopDown(nn.Module):
         plan, io = eng._train_plan(B)
         # every parameter gradient is linear in the heat-map gradient the forward half left behind:
         # seeding with the incoming dL/dloss there costs one small device op and no host sync
-        io['dheat'].mul_(g.to(io['dheat'].dtype))
+        for j, dh in enumerate(io['dheats']):
+            dh.mul_((g[j] if g.dim() else g).to(dh.dtype))
         plan.run(first=eng.n_fwd_calls)
         st = eng.store
         if self._stash is not None:
@@ -1179,18 +1268,19 @@ class TopDown(nn.Module):
         """test_cfg['fp32_exact'] (extension): evaluate at the reference's fp32 accuracy instead of bf16."""
         return bool((self.test_cfg or {}).get('fp32_exact', False))
 
-    def _infer_heatmap(self, img, flip_pairs=None):
+    def _infer_heatmap(self, img, flip_pairs=None, img_metas=None):
         """backbone + head.inference_model (-> host array); one fused plan when available."""
         if self._engine is not None and not self.training:
             _need_hip(img, 'TopDown.forward_test')
             self._refresh()
-            heat = self._engine.infer(img.float(), copy_out=False, exact=self._exact()).cpu().numpy()
+            heat = self._engine.infer(img.float(), copy_out=False, exact=self._exact(),
+                                      dataset_source=self._src_of(img_metas)).cpu().numpy()
             if flip_pairs is not None:
                 heat = flip_back(heat, flip_pairs, target_type=self.keypoint_head.target_type)
                 if self.keypoint_head.test_cfg.get('shift_heatmap', False):
                     heat[:, :, :, 1:] = heat[:, :, :, :-1]
             return heat
-        features = self.backbone(img)
+        features = self._backbone(img, img_metas)
         if self.with_neck:
             features = self.neck(features)
         return self.keypoint_head.inference_model(features, flip_pairs=flip_pairs)
@@ -1212,17 +1302,18 @@ class TopDown(nn.Module):
             _need_hip(img, 'TopDown.forward_test')
             self._refresh()
             x = img.float()
-            heat = self._engine.infer(x, exact=self._exact())          # a copy: the plan's buffer is reused
+            src = self._src_of(img_metas)
+            heat = self._engine.infer(x, exact=self._exact(), dataset_source=src)   # a copy: the plan's buffer is reused
             if flip:
-                hf = self._engine.infer(x.flip(3), copy_out=False, exact=self._exact())
+                hf = self._engine.infer(x.flip(3), copy_out=False, exact=self._exact(), dataset_source=src)
                 heat = flip_back_avg_device(heat, hf, img_metas[0]['flip_pairs'],
                                             head.test_cfg.get('shift_heatmap', False))
             result.update(head.decode(img_metas, heat, img_size=[img_width, img_height]))
             result['output_heatmap'] = heat.cpu().numpy() if return_heatmap else None
             return result
-        output_heatmap = self._infer_heatmap(img)
+        output_heatmap = self._infer_heatmap(img, img_metas=img_metas)
         if flip:
-            output_flipped_heatmap = self._infer_heatmap(img.flip(3), img_metas[0]['flip_pairs'])
+            output_flipped_heatmap = self._infer_heatmap(img.flip(3), img_metas[0]['flip_pairs'], img_metas)
             output_heatmap = (output_heatmap + output_flipped_heatmap) * 0.5
         if self.with_keypoint:
             result.update(self.keypoint_head.decode(img_metas, output_heatmap, img_size=[img_width, img_height]))
@@ -1303,6 +1394,85 @@ class TopDown(nn.Module):
         if self._engine is None:
             raise RuntimeError('enable_ddp needs the fused model on a HIP device (model.cuda())')
         return self._engine.enable_ddp(process_group, blocks_per_bucket)
+
+
+@POSENETS.register_module()
+class TopDownMoE(TopDown):
+    """ViTPose+ detector (top_down_moe.py:26-262): a ViTMoE backbone routed by img_metas[i]['dataset_idx'], the
+    main head for dataset 0 and one associate head per further dataset; every head sees every image, its loss
+    only the images of its own dataset (targets and target weights of the others are zeroed)."""
+
+    def __init__(self, backbone, neck=None, keypoint_head=None, associate_keypoint_head=None, train_cfg=None,
+                 test_cfg=None, pretrained=None, loss_pose=None):
+        super().__init__(backbone, neck, keypoint_head, train_cfg, test_cfg, pretrained, loss_pose)
+        heads = []
+        if associate_keypoint_head is not None:
+            if not isinstance(associate_keypoint_head, list):
+                associate_keypoint_head = [associate_keypoint_head]
+            for cfg in associate_keypoint_head:
+                cfg['train_cfg'] = train_cfg
+                cfg['test_cfg'] = test_cfg
+                heads.append(build_head(cfg))
+        self.associate_keypoint_heads = nn.ModuleList(heads)
+        self.keypoint_heads_cnt = 1 + len(heads)
+        for h in heads:
+            h.init_weights()
+
+    def init_weights(self, pretrained=None):
+        super().init_weights(pretrained)
+        for h in getattr(self, 'associate_keypoint_heads', []):
+            h.init_weights()
+
+    def _src_of(self, img_metas):
+        return [int(m['dataset_idx']) for m in img_metas]
+
+    def _backbone(self, img, img_metas=None):
+        if img_metas is None:
+            return self.backbone(img)
+        return self.backbone(img, torch.as_tensor(self._src_of(img_metas), device=img.device))
+
+    def forward_train(self, img, target, target_weight, img_metas, **kwargs):
+        """top_down_moe.py:166-203."""
+        src_host = self._src_of(img_metas)
+        src = torch.as_tensor(src_host, device=img.device)
+        names = [('main_stream_loss', 'main_stream_acc')] + \
+                [(f'{i}_loss', f'{i}_acc') for i in range(1, self.keypoint_heads_cnt)]
+        heads = [h for _, h in self._heads()]
+        losses = dict()
+        fused = self._engine is not None and self.training and torch.is_grad_enabled()
+        if fused:
+            _need_hip(img, 'TopDownMoE.forward_train')
+            assert target.dim() == 4 and target_weight.dim() == 3
+            self._src = src_host
+            try:
+                loss = _FusedTrainFunction.apply(self, img.float(), target.float(), target_weight.float(),
+                                                 *self.parameters())
+            finally:
+                self._src = None
+            loss = loss.reshape(-1)
+            outputs = self._heats
+        else:
+            feat = self._backbone(img, img_metas)
+            if self.with_neck:
+                feat = self.neck(feat)
+        skip_acc = (self.train_cfg or {}).get('skip_accuracy', False)
+        for i, (head, (ln, an)) in enumerate(zip(heads, names)):
+            sel = (src == i)
+            t_sel = target * sel.view(-1, 1, 1, 1)
+            w_sel = target_weight * sel.view(-1, 1, 1)
+            if fused:
+                losses[ln] = loss[i]
+                out = outputs[i]
+            else:
+                out = head(feat)
+                losses[ln] = head.get_loss(out, t_sel, w_sel)['heatmap_loss']
+            if not (fused and skip_acc):
+                losses[an] = head.get_accuracy(out, t_sel, w_sel)['acc_pose']
+        return losses
+
+    def forward_dummy(self, img):
+        """top_down_moe.py:246-262 (the reference passes no dataset index there; dataset 0 is used)."""
+        return super().forward_dummy(img)
 
 
 class _FlatOptimizer:

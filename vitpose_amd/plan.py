@@ -199,8 +199,18 @@ class Plan:
     def gemm(self, x, y, out, M, N, K, *, ldx, ldy, ldo, x_kmajor=False, y_kmajor=False,
              epilogue=_lib.VP_EPI_BF16, out2=None, bias=None, colscale=None, resid=None,
              rowscale=None, rows_per_scale=0, aux=None, ldaux=0, pos=None, pos_rows=0, split_k=1,
-             row_map=None, split_stride=0, tail_force=False, tile_mode=0):
+             row_map=None, split_stride=0, tail_force=False, tile_mode=0, route=None):
+        """route = (expert [images] int32, delta [experts] int64, bias_delta [experts] int64 or None, split):
+        per-image routing of the Y operand (mixture-of-experts FFN; see vp_gemm_args in the header)."""
         a = GemmArgs()
+        if route is not None:
+            r_exp, r_delta, r_bdelta, r_split = route
+            _chk(r_exp, torch.int32, 'route expert'), _chk(r_delta, torch.int64, 'route delta')
+            _chk(r_bdelta, torch.int64, 'route bias delta')
+            a.route_expert, a.route_delta, a.route_split = r_exp.data_ptr(), r_delta.data_ptr(), int(r_split)
+            a.route_bias_delta = r_bdelta.data_ptr() if r_bdelta is not None else None
+            self.keep.extend(t for t in (r_exp, r_delta, r_bdelta) if t is not None)
+            tile_mode = 3
         a.tail_force = int(tail_force)
         a.tile_mode = int(tile_mode)
         a.split_stride = split_stride
@@ -273,14 +283,19 @@ class Plan:
 
     def wgrad_group(self, problems, K, tile_mode=0):
         """One launch for several independent weight gradients out_i [M_i][N_i] = x_i^T y_i over a common
-        reduction extent K.  problems: list of (x [K][M] bf16, y [K][N] bf16, out f32, M, N, ldx, ldy[, rowsum]);
-        rowsum (f32 [M], optional) receives sum_k x[k][m], the bias gradient of the same Linear."""
+        reduction extent K.  problems: list of (x [K][M] bf16, y [K][N] bf16, out f32, M, N, ldx, ldy[, rowsum
+        [, kmap, nk]]); rowsum (f32 [M], optional) receives sum_k x[k][m], the bias gradient of the same Linear;
+        kmap / nk (int32 device tensors, optional): the problem reduces over the 64-row K tiles that start at rows
+        kmap[0 .. nk[0]) only (expert weight gradients: the tokens of the images routed to that expert)."""
         from ._lib import GroupEntry
         if len(problems) > 64:               # the kernel maps a workgroup to its problem with one 64-lane ballot
             self.wgrad_group(problems[:64], K, tile_mode)
             return self.wgrad_group(problems[64:], K, tile_mode)
         n = len(problems)
         dev = problems[0][2].device
+        mapped = any(len(p) > 8 and p[8] is not None for p in problems)
+        if mapped:
+            tile_mode = 3
 
         def table(mode):
             arr = (GroupEntry * n)()
@@ -291,6 +306,9 @@ class Plan:
                 if len(prob) > 7 and prob[7] is not None:
                     _chk(prob[7], torch.float32, 'rowsum')
                     g.rowsum = prob[7].data_ptr()
+                if len(prob) > 8 and prob[8] is not None:
+                    _chk(prob[8], torch.int32, 'kmap'), _chk(prob[9], torch.int32, 'nk')
+                    g.kmap, g.nk_dev = prob[8].data_ptr(), prob[9].data_ptr()
             total = ctypes.c_int(0)
             rc = self.L.vp_wgrad_group_table(arr, n, mode, ctypes.byref(total))
             if rc != 0:
@@ -307,11 +325,14 @@ class Plan:
                     for mode in (2, 3)})
             tile_mode = _TUNE_CACHE.get(key, 3)
         blob, total = table(tile_mode)
-        keep = [blob] + [t for p in problems for t in p[:3]] + [p[7] for p in problems if len(p) > 7]
+        keep = [blob] + [t for p in problems for t in p[:3]] + [t for p in problems for t in p[7:]]
         # timing tag in the (x_kmajor, y_kmajor, epilogue, M, N, K) form of gemm(): epilogue 100 = grouped,
         # M * N = summed output elements
         self.tags[len(self.calls)] = (1, 1, 100, sum(p[3] * p[4] for p in problems), 1, K)
-        self._add('vp_wgrad_grouped_bf16', _p(blob), n, total, K, tile_mode, keep=tuple(keep))
+        if mapped:
+            self._add('vp_wgrad_grouped_kmap_bf16', _p(blob), n, total, K, keep=tuple(keep))
+        else:
+            self._add('vp_wgrad_grouped_bf16', _p(blob), n, total, K, tile_mode, keep=tuple(keep))
 
     def layernorm_fwd(self, x, gamma, beta, y_bf16, y_f32, mean, rstd, M, E, eps=1e-6):
         _chk(x, torch.float32, 'x')
@@ -339,12 +360,13 @@ class Plan:
         self._add('vp_patch_im2col', _p(img), _p(col), B, C, H, W, patch, stride, pad, keep=(img, col))
 
     # -- fp32-accurate path (hi / lo bf16 operand pairs) --
-    def gemm3(self, xh, xl, wh, wl, acc, M, N, K, *, ldx, ldy, ldo, bias=None):
+    def gemm3(self, xh, xl, wh, wl, acc, M, N, K, *, ldx, ldy, ldo, bias=None, route=None):
         """acc (f32) = x w^T + bias with x = xh + xl, w = wh + wl: three MFMA GEMMs chained through
         the f32 accumulate epilogue (the lo * lo term, ~2^-16 relative, is dropped)."""
-        self.gemm(xh, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_F32, bias=bias)
-        self.gemm(xh, wl, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc)
-        self.gemm(xl, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc)
+        self.gemm(xh, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_F32, bias=bias, route=route)
+        nb = (route[0], route[1], None, route[3]) if route is not None else None   # the bias is added once
+        self.gemm(xh, wl, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc, route=nb)
+        self.gemm(xl, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc, route=nb)
 
     def finish_f32(self, x, M, N, *, ldx, ldo, out=None, hi=None, lo=None, colscale=None, colshift=None, act=0,
                    resid=None, ldr=0, rowscale=None, rows_per_scale=0, row_map=None):

@@ -17,30 +17,43 @@ from .plan import Plan
 
 class PoseEngine:
     def __init__(self, vit_cfg: dict, head_cfg: dict, device='cuda', loss_weight: float = 1.0,
-                 use_target_weight: bool = True):
+                 use_target_weight: bool = True, assoc_heads=()):
+        """assoc_heads: [(head_cfg, loss_weight, use_target_weight)] = the `associate_keypoint_head` list of
+        TopDownMoE (top_down_moe.py:75-89): head j + 1 is trained on the images whose dataset index is j + 1."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('PoseEngine runs on an MI355X (HIP device) only; there is no CPU path')
         _lib.lib()  # fail loudly now if the HIP library is missing
         self.vit_cfg, self.head_cfg = dict(vit_cfg), dict(head_cfg)
         self.loss_weight, self.use_target_weight = loss_weight, use_target_weight
-        hp, hb = head_param_shapes(head_cfg)
-        named = [('backbone.' + n, s) for n, s in vit_param_shapes(vit_cfg)] + \
-                [('keypoint_head.' + n, s) for n, s in hp]
+        head_specs = [('keypoint_head.', dict(head_cfg), loss_weight, use_target_weight)] + \
+                     [(f'associate_keypoint_heads.{j}.', dict(c), lw, utw) for j, (c, lw, utw) in enumerate(assoc_heads)]
+        named = [('backbone.' + n, s) for n, s in vit_param_shapes(vit_cfg)]
+        self.buffers = {}
+        for pre, cfg, _, _ in head_specs:
+            hp, hb = head_param_shapes(cfg)
+            named += [(pre + n, s) for n, s in hp]
+            self.buffers.update({pre + n: (torch.ones if n.endswith('var') else torch.zeros)(
+                s, dtype=torch.float32, device=self.device) for n, s in hb})
         self.store = ParamStore(named, self.device)
-        self.buffers = {'keypoint_head.' + n: (torch.ones if n.endswith('var') else torch.zeros)(
-            s, dtype=torch.float32, device=self.device) for n, s in hb}
         self.vit = VitRunner(vit_cfg, self.store, 'backbone.')
-        self.head = HeadRunner(head_cfg, self.store, self.buffers, (self.vit.Hp, self.vit.Wp), 'keypoint_head.')
+        self.heads = [HeadRunner(cfg, self.store, self.buffers, (self.vit.Hp, self.vit.Wp), pre)
+                      for pre, cfg, _, _ in head_specs]
+        self.head_loss = [(lw, utw) for _, _, lw, utw in head_specs]
+        self.head = self.heads[0]
         self.K = head_cfg['out_channels']
+        self.routed = self.vit.part > 0          # ViTMoE backbone: every pass needs the images' dataset indices
+        self.multi = self.routed or len(self.heads) > 1
         self.ws_train = Workspace(self.device)
+        self.ws_heads = [self.ws_train] + [Workspace(self.device) for _ in self.heads[1:]]
         self.ws_infer = Workspace(self.device)
         self.plans = {}
         self.prep = Plan()
         self.prep.cast_f32_bf16(self.store.data, self.store.half, self.store.numel)
-        self.head.record_weight_prep(self.prep)
         self.prep_derived = Plan()  # after an optimizer step the bf16 mirror is already fresh
-        self.head.record_weight_prep(self.prep_derived)
+        for h in self.heads:
+            h.record_weight_prep(self.prep)
+            h.record_weight_prep(self.prep_derived)
         self.prep_exact = None      # lo halves of the weights, built on the first exact evaluation
         self.optimizer = None
         self.comm = None
@@ -116,11 +129,15 @@ class PoseEngine:
         return self.plans[key]
 
     @torch.no_grad()
-    def infer(self, img: torch.Tensor, copy_out: bool = True, exact: bool = False) -> torch.Tensor:
-        """img [B,3,H,W] f32 on the device -> heatmaps [B,K,4Hp,4Wp] f32 (eval-mode BN).
-        exact=True evaluates at fp32 accuracy (see _exact_plan)."""
+    def infer(self, img: torch.Tensor, copy_out: bool = True, exact: bool = False,
+              dataset_source=None) -> torch.Tensor:
+        """img [B,3,H,W] f32 on the device -> heatmaps [B,K,4Hp,4Wp] f32 (eval-mode BN) of the main head.
+        exact=True evaluates at fp32 accuracy (see _exact_plan).  dataset_source: per-image dataset indices
+        (ViTMoE backbone: selects the FFN expert, vit_moe.py:98-115; None = dataset 0)."""
         B = img.shape[0]
         plan, img_in, heat = self._exact_plan(B) if exact else self._infer_plan(B)
+        if self.routed:
+            self.vit.set_routing(self.ws_infer, B, dataset_source if dataset_source is not None else [0] * B)
         if exact:
             self.prep_exact.run()
         if img.data_ptr() != img_in.data_ptr():
@@ -136,20 +153,49 @@ class PoseEngine:
             H, W = self.vit.img_hw
             oh, ow = self.head.out_grid
             io = dict(img=ws.f32('img', B, self.vit.C, H, W), target=ws.f32('target', B, self.K, oh, ow),
-                      tw=ws.f32('tw', B, self.K), heat=ws.f32('heat', B, self.K, oh, ow),
-                      loss=ws.f32('loss', 1), dp=ws.f32('dp', self.vit.depth, 2, B))
+                      tw=ws.f32('tw', B, self.K), dp=ws.f32('dp', self.vit.depth, 2, B))
             io['dp'].fill_(1.0)
+            nh = len(self.heads)
+            # per head: heat maps, loss, (masked) target weights; head 0's are also io['heat'] / ['loss'] / ['tw']
+            io['heats'] = [hw.f32('heat', B, h.K, oh, ow) for h, hw in zip(self.heads, self.ws_heads)]
+            io['losses'] = [hw.f32('loss', 1) for hw in self.ws_heads]
+            io['tws'] = [io['tw']] + [hw.f32('tw_sel', B, self.K) for hw in self.ws_heads[1:]]
+            # a loss without target weights sees the masked TARGET (top_down_moe.py:181,193), so it needs a copy
+            io['targets'] = [io['target'] if (utw or not self.multi) else hw.f32('target_sel', B, self.K, oh, ow)
+                             for (_, utw), hw in zip(self.head_loss, self.ws_heads)]
+            io['heat'], io['loss'] = io['heats'][0], io['losses'][0]
             plan = Plan()
             if self.side_stream_wgrad:
                 plan.enable_side_stream(self.device)
             plan.memset0(self.store.grad)
             feat = self.vit.record_forward(plan, ws, io['img'], B, training=True, dp=io['dp'])
-            dheat = self.head.record_forward(plan, ws, feat, B, True, io['heat'], io['target'],
-                                             io['tw'] if self.use_target_weight else None, io['loss'],
-                                             want_grad=True, loss_weight=self.loss_weight)
+            dheats = []
+            for j, (h, hw) in enumerate(zip(self.heads, self.ws_heads)):
+                if h.K != self.K or h.out_grid != (oh, ow):
+                    raise ValueError(f'head {j} emits {h.K} heat maps of {h.out_grid}; the batch carries one target of '
+                                     f'{self.K} x {(oh, ow)} for every head (top_down_moe.py:181-197)')
+                lw, utw = self.head_loss[j]
+                dheats.append(h.record_forward(plan, hw, feat, B, True, io['heats'][j], io['targets'][j],
+                                               io['tws'][j] if utw else None, io['losses'][j],
+                                               want_grad=True, loss_weight=lw))
             self.n_fwd_calls = len(plan)
-            io['dheat'] = dheat
-            dfeat = self.head.record_backward(plan, ws, feat, dheat, B)
+            io['dheats'] = dheats
+            io['dheat'] = dheats[0]
+            dfeats = [h.record_backward(plan, hw, feat, dh, B) for h, hw, dh in zip(self.heads, self.ws_heads, dheats)]
+            dfeat = dfeats[0]
+            if nh > 1:
+                # every head reads the same feature map: its gradient is the sum over the heads (a small
+                # elementwise add, f32 accumulation)
+                acc = ws.f32('dfeat_sum_f32', *dfeat.shape)
+                dsum = ws.bf16('dfeat_sum', *dfeat.shape)
+
+                def add_up():
+                    acc.copy_(dfeats[0])
+                    for d in dfeats[1:]:
+                        acc.add_(d)
+                    dsum.copy_(acc)
+                plan.host(add_up)
+                dfeat = dsum
             comm = self.comm
             self.vit.record_backward(plan, ws, dfeat, B, dp=io['dp'],
                                      after_block=comm.after_block if comm is not None else None,
@@ -159,15 +205,35 @@ class PoseEngine:
             self.plans[key] = (plan, io)
         return self.plans[key]
 
-    def forward_backward(self, img, target, target_weight, drop_path: bool = True, dp_scales=None,
-                         generator=None, timers=None):
-        """One training forward + backward.  Gradients land in self.store.grad (zeroed first);
-        returns (loss [1] device tensor, heatmaps [B,K,H,W] device tensor; both are plan-owned)."""
+    def load_batch(self, io, img, target, target_weight, dataset_source=None):
+        """Copy one batch into the plan's input buffers; with several heads / a routed backbone also the
+        per-head selections of TopDownMoE.forward_train (top_down_moe.py:177-197): head j is trained on the
+        images whose dataset index is j, every other image's target weights (and targets) are zeroed."""
         B = img.shape[0]
-        plan, io = self._train_plan(B)
         for k, t in (('img', img), ('target', target), ('tw', target_weight.reshape(B, self.K))):
             if t.data_ptr() != io[k].data_ptr():
                 io[k].copy_(t)
+        if not self.multi:
+            return
+        src = dataset_source if dataset_source is not None else [0] * B
+        if self.routed:
+            self.vit.set_routing(self.ws_train, B, src)
+        src_t = torch.as_tensor(src, device=self.device).reshape(B)
+        tw0 = io['tw'].clone() if len(self.heads) > 1 else io['tw']
+        for j in range(len(self.heads)):
+            sel = (src_t == j).to(torch.float32)
+            if io['targets'][j] is not io['target']:
+                torch.mul(io['target'], sel.view(B, 1, 1, 1), out=io['targets'][j])
+            torch.mul(tw0, sel.view(B, 1), out=io['tws'][j])
+
+    def forward_backward(self, img, target, target_weight, drop_path: bool = True, dp_scales=None,
+                         generator=None, timers=None, dataset_source=None):
+        """One training forward + backward.  Gradients land in self.store.grad (zeroed first);
+        returns (loss [1] device tensor, heatmaps [B,K,H,W] device tensor; both are plan-owned) -- with
+        associate heads, the lists of both over the heads."""
+        B = img.shape[0]
+        plan, io = self._train_plan(B)
+        self.load_batch(io, img, target, target_weight, dataset_source)
         if dp_scales is not None:
             io['dp'].copy_(dp_scales)
         elif drop_path and max(self.vit.dp_rates) > 0:
@@ -178,6 +244,8 @@ class PoseEngine:
             plan.run_timed(timers)
         else:
             plan.run()
+        if len(self.heads) > 1:
+            return io['losses'], io['heats']
         return io['loss'], io['heat']
 
     def setup_optimizer(self, lr=5e-4, betas=(0.9, 0.999), weight_decay=0.1, layer_decay_rate=0.75,
