@@ -60,6 +60,19 @@ def model_cfg(m):
                       modulate_kernel=11, use_udp=False))
 
 
+def plus_model_cfg(m, heads=6):
+    """The `model` block of configs/.../coco/vitPose+_base_coco+aic+mpii+ap10k+apt36k+wholebody_256x192_udp.py:
+    TopDownMoE, a ViTMoE backbone with 6 experts on the last quarter of the FFN output channels, the main head and
+    five associate heads.  Every head emits 17 heat maps here: the detector's forward_train feeds ONE target tensor
+    to all heads (top_down_moe.py:181-197), so a trainable batch needs equal keypoint counts."""
+    cfg = model_cfg(m)
+    cfg['type'] = 'TopDownMoE'
+    cfg['backbone'].update(type='ViTMoE', num_expert=6, part_features=m['embed_dim'] // 4)
+    cfg['associate_keypoint_head'] = [dict(cfg['keypoint_head'], loss_keypoint=dict(cfg['keypoint_head']['loss_keypoint']))
+                                      for _ in range(heads - 1)]
+    return cfg
+
+
 def cpu_baseline(model_key, batch, mode, iters=3):
     """The CPU oracle (torch fp32 restatement of the reference ops) timed on this box's host cores
     on a bounded sample of the same workload."""
@@ -119,6 +132,8 @@ def main():
     ap.add_argument('--mode', default='train', choices=['train', 'infer'])
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--plus', action='store_true',
+                    help='ViTPose+ (ViTMoE backbone, TopDownMoE detector with 6 heads) instead of the headline model')
     ap.add_argument('--cpu-batch', type=int, default=8)
     args = ap.parse_args()
 
@@ -138,7 +153,10 @@ def main():
     from vitpose_amd.builder import build_posenet
     m = MODELS[args.model]
     torch.manual_seed(0)                                    # identical random-init replicas on every rank
-    model = build_posenet(model_cfg(m)).to(dev)             # reference init: trunc_normal .02 / head normal .001
+    # reference init: trunc_normal .02 / head normal .001
+    model = build_posenet(plus_model_cfg(m) if args.plus else model_cfg(m)).to(dev)
+    metas = [dict(dataset_idx=i % 6) for i in range(args.batch)] if args.plus else None
+    loss_keys = ['main_stream_loss'] + [f'{i}_loss' for i in range(1, 6)] if args.plus else ['heatmap_loss']
     eng = model._engine
     assert eng is not None, 'the fused HIP plan must be active'
     B = args.batch
@@ -158,15 +176,23 @@ def main():
             model.enable_ddp()
 
         def step():
-            losses = model.forward_train(img, target, tw, None)
-            losses['heatmap_loss'].backward()
+            losses = model.forward_train(img, target, tw, metas)
+            loss = sum(losses[k] for k in loss_keys)
+            loss.backward()
             opt.step()
             opt.zero_grad()
-            return losses['heatmap_loss']
+            return loss
         plan_of = lambda: eng.plans[('train', B)][0]  # noqa: E731
         gflop = m['train_gflop']
         what = (f'ViTPose-{args.model} 256x192 classic-decoder training step (fwd+bwd+grad-clip+AdamW, DropPath on, '
                 f'BN batch stats) via TopDown.forward_train, {B} img/GPU, global batch {world * B}, random-init weights')
+        if args.plus:
+            E = m['embed_dim']
+            head_gmac = (192 * E * 256 * 16 + 768 * 256 * 256 * 16 + 3072 * 256 * 17) / 1e9
+            gflop += 5 * 6 * head_gmac      # five more heads, forward + both backward products
+            what = (f'ViTPose+-{args.model} (ViTMoE: 6 experts on {E // 4} FFN channels; TopDownMoE: 6 classic heads, '
+                    f'images spread evenly over 6 datasets) training step via TopDownMoE.forward_train, {B} img/GPU, '
+                    f'global batch {world * B}, random-init weights')
     else:
         model.eval()
 
@@ -256,7 +282,7 @@ def main():
         }
         if args.mode == 'train':
             out['loss'] = float(last.item())
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.plus:
             out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_batch, args.mode)
         print(json.dumps(out))
     if world > 1:

@@ -223,15 +223,15 @@ typedef struct vp_group_entry {
     int ldx, ldy, ldo, M, N;
     int tiles_n, ntiles, tile0;   /* filled by vp_wgrad_group_table */
     float* rowsum;                /* optional [M]: rowsum[m] = sum_k x[k][m], the bias gradient of the same Linear */
-    /* vp_wgrad_grouped_kmap_bf16 only (else NULL): this problem reduces over a list of 64-row K tiles instead of
-     * all K rows: kmap[t] = first row of its t-th tile, *nk_dev = the number of tiles (device memory both, so a
-     * recorded launch follows per-step routing; 0 tiles = zeros are written). */
-    const int* kmap; const int* nk_dev;
+    /* vp_wgrad_grouped_kmap_bf16 only (else NULL): the K rows are images of tiles_per_image * 64 rows each, and
+     * this problem reduces over the images whose bit is set in image_mask (ceil(images / 64) 64-bit words in DEVICE
+     * memory, so a recorded launch follows per-step routing; no bit set = zeros are written). */
+    const unsigned long long* image_mask; int tiles_per_image;
 } vp_group_entry;                 /* 80 bytes */
 int vp_wgrad_group_table(vp_group_entry* problems_host, int count, int tile_mode, int* total_tiles);
 int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K, int tile_mode,
                           vp_stream_t stream);
-/* The same launch (192 x 192 tiles) for tables in which some problems carry a K-tile list: the expert weight
+/* The same launch (192 x 192 tiles) for tables in which some problems carry an image mask: the expert weight
  * gradients of the mixture-of-experts FFN (vit_moe.py:92-96,108-111 under autograd: expert e only receives
  * gradient from the images routed to it).  K = rows of the operands (upper bound of every list). */
 int vp_wgrad_grouped_kmap_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K,

@@ -206,3 +206,65 @@ def test_reference_config_files_build_unchanged():
             assert pw['num_layers'] == cfg.model['backbone']['depth']
         built += 1
     assert built >= 10
+
+
+def test_vit_moe_contract_and_reference_plus_config():
+    """ViTMoE / TopDownMoE: state-dict keys and shapes of vit_moe.py:78-96, the constructor error, the routing
+    tables, the expert split of a plain-ViT checkpoint (mmcv_custom/checkpoint.py:396-404), and the reference's
+    ViTPose+ config file built unchanged (where the reference tree exists)."""
+    import os
+    import numpy as np
+    from vitpose_amd.builder import build_backbone, build_posenet
+    from vitpose_amd.checkpoint import split_expert_state_dict
+    with pytest.raises(TypeError):
+        build_backbone(dict(type='ViTMoE', img_size=(256, 192), embed_dim=64, depth=1, num_heads=2, num_expert=2))
+    m = build_backbone(dict(type='ViTMoE', img_size=(256, 192), patch_size=16, embed_dim=192, depth=2, num_heads=6,
+                            mlp_ratio=4, qkv_bias=True, num_expert=3, part_features=48))
+    sd = m.state_dict()
+    assert sd['blocks.1.mlp.fc2.weight'].shape == (144, 768) and sd['blocks.1.mlp.fc2.bias'].shape == (144,)
+    assert sd['blocks.0.mlp.experts.2.weight'].shape == (48, 768) and sd['blocks.0.mlp.experts.2.bias'].shape == (48,)
+    assert 'blocks.0.mlp.experts.3.weight' not in sd
+    # oracle and engine agree on the parameter list
+    from oracle import vitpose_oracle as O
+    from vitpose_amd.engine import ParamStore, VitRunner, Workspace, vit_param_shapes
+    assert vit_param_shapes(m._cfg) == O.vit_param_shapes(m._cfg)
+    assert [k for k, _ in vit_param_shapes(m._cfg)] == list(sd.keys())
+    # a plain ViT state dict enters the experts: shared rows first, the last part_features rows to every expert
+    plain = build_backbone(dict(type='ViT', img_size=(256, 192), patch_size=16, embed_dim=192, depth=2, num_heads=6,
+                                mlp_ratio=4, qkv_bias=True))
+    psd = {k: torch.randn_like(v) for k, v in plain.state_dict().items()}
+    new = split_expert_state_dict(m, psd, 48)
+    assert torch.equal(new['blocks.1.mlp.fc2.weight'], psd['blocks.1.mlp.fc2.weight'][:144])
+    assert torch.equal(new['blocks.1.mlp.experts.1.weight'], psd['blocks.1.mlp.fc2.weight'][144:])
+    assert torch.equal(new['blocks.0.mlp.experts.2.bias'], psd['blocks.0.mlp.fc2.bias'][144:])
+    missing, unexpected = m.load_state_dict(new, strict=True)
+    # routing tables: per expert the bit mask of its images, and the offsets of the expert rows
+    st = ParamStore(vit_param_shapes(m._cfg), 'cpu')
+    vr = VitRunner(m._cfg, st)
+    ws = Workspace('cpu')
+    vr.set_routing(ws, 4, [2, 0, 2, 1])
+    expert, mask = vr.route_buffers(ws, 4)
+    assert expert.tolist() == [2, 0, 2, 1] and mask.tolist() == [[0b0010], [0b1000], [0b0101]]
+    off = st.offsets
+    assert int(vr.moe_delta[1][2]) == off['blocks.1.mlp.experts.2.weight'] - off['blocks.1.mlp.fc2.weight'] - 144 * 768
+    assert int(vr.moe_bdelta[0][0]) == off['blocks.0.mlp.experts.0.bias'] - off['blocks.0.mlp.fc2.bias'] - 144
+    assert all(int(d) % 8 == 0 for d in vr.moe_delta[0])
+    with pytest.raises(ValueError):
+        vr.set_routing(ws, 4, [0, 1, 3, 0])          # dataset index outside num_expert
+    with pytest.raises(ValueError):
+        vr.set_routing(ws, 4, [0, 1])
+    root = os.environ.get('VITPOSE_REFERENCE_ROOT', '/root/reference')
+    f = os.path.join(root, 'configs/body/2d_kpt_sview_rgb_img/topdown_heatmap/coco',
+                     'vitPose+_small_coco+aic+mpii+ap10k+apt36k+wholebody_256x192_udp.py')
+    if not os.path.isfile(f):
+        return
+    from vitpose_amd.config import Config
+    cfg = Config.fromfile(f)
+    det = build_posenet(dict(cfg.model))
+    assert type(det).__name__ == 'TopDownMoE' and det.keypoint_heads_cnt == 6
+    assert [h.final_layer.weight.shape[0] for h in det.associate_keypoint_heads] == [14, 16, 17, 17, 133]
+    part = cfg.model['backbone']['part_features']
+    assert det.backbone.blocks[0].mlp.experts[5].weight.shape == (part, 1536)
+    assert det.backbone.blocks[0].mlp.fc2.weight.shape == (384 - part, 1536)
+    names = [n for n, _ in det.named_parameters()]
+    assert 'associate_keypoint_heads.4.final_layer.weight' in names

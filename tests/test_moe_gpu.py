@@ -103,25 +103,24 @@ def test_routed_gemm_exact(dev, E, P, Hd, nexp):
 
 def test_grouped_wgrad_kmap_exact(dev):
     """Expert weight gradients: every expert reduces over the K tiles of its own images only (an expert without
-    images gets zeros), next to an ordinary problem in the same launch; row sums = the bias gradients."""
-    E, P, Hd, nexp, B, T = 192, 48, 128, 4, 6, 192
+    images gets zeros), next to an ordinary problem in the same launch; row sums = the bias gradients.  70 images:
+    the image masks span two 64-bit words."""
+    E, P, Hd, nexp, B, T = 192, 48, 128, 4, 70, 192
     Ns, M = E - P, B * T
-    src = [2, 0, 2, 1, 0, 2]                      # expert 3 has no image
+    src = [(2, 0, 2, 1, 0, 2, 2)[b % 7] if b != 64 else 1 for b in range(B)]     # expert 3 has no image
     dxb = ints((M, E), dev, seed=1).bfloat16()
     h = ints((M, Hd), dev, seed=2).bfloat16()
-    km = np.zeros((nexp, 3 * B), np.int32)
-    cnt = np.zeros(nexp, np.int32)
+    words = np.zeros((nexp, 2), np.uint64)
     for b, e in enumerate(src):
-        km[e, cnt[e]:cnt[e] + 3] = b * T + np.arange(3) * 64
-        cnt[e] += 3
-    kmap, nk = torch.from_numpy(km).to(dev), torch.from_numpy(cnt).to(dev)
+        words[e, b // 64] |= np.uint64(1) << np.uint64(b % 64)
+    mask = torch.from_numpy(words.view(np.int64)).to(dev)
     g_sh = torch.full((Ns, Hd), float('nan'), device=dev)
     b_sh = torch.full((Ns,), float('nan'), device=dev)
     g_e = [torch.full((P, Hd), float('nan'), device=dev) for _ in range(nexp)]
     b_e = [torch.full((P,), float('nan'), device=dev) for _ in range(nexp)]
     xe = dxb.view(-1)[Ns:]
     probs = [(dxb, h, g_sh, Ns, Hd, E, Hd, b_sh)] + \
-            [(xe, h, g_e[e], P, Hd, E, Hd, b_e[e], kmap[e], nk[e:e + 1]) for e in range(nexp)]
+            [(xe, h, g_e[e], P, Hd, E, Hd, b_e[e], mask[e], T // 64) for e in range(nexp)]
     run(lambda p: p.wgrad_group(probs, M))
     d, hf = dxb.float(), h.float()
     assert torch.equal(g_sh, d[:, :Ns].t() @ hf)

@@ -42,7 +42,7 @@ class GroupEntry(Structure):
     _fields_ = [('x', c_void_p), ('y', c_void_p), ('out', c_void_p),
                 ('ldx', c_int), ('ldy', c_int), ('ldo', c_int), ('M', c_int), ('N', c_int),
                 ('tiles_n', c_int), ('ntiles', c_int), ('tile0', c_int), ('rowsum', c_void_p),
-                ('kmap', c_void_p), ('nk_dev', c_void_p)]
+                ('image_mask', c_void_p), ('tiles_per_image', c_int)]
 
 
 SIGNATURES = {

@@ -952,8 +952,9 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s,
 }
 
 // ROUTE: per-image Y routing (see Route; a row tile is exactly one image of 192 tokens).
-// KMAP (grouped weight gradients only): a problem may reduce over a LIST of 64-token K tiles, kmap[t] = first
-// token row of its t-th tile, *nk_dev = their count (0 = the output is written as zeros).
+// KMAP (grouped weight gradients only): a problem may reduce over a SUBSET of the images whose rows make up the
+// K extent: bit b of its image_mask words selects image b (tiles_per_image K tiles each; no bit set = the output
+// is written as zeros).  The K loop walks the set bits with scalar ALU work only (no memory access in the loop).
 template <bool XKMAJ, bool YKMAJ, int EPI, bool ROUTE = false, bool KMAP = false>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Operand Y, int M, int N, int K,
                                                                 int tiles_n, int ntiles, int ksplit_tiles, Epi e,
@@ -982,13 +983,39 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     const int kt0 = slice * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
     int nk = kt1 - kt0;
-    const int* kmap = nullptr;
+    // image iterator of a masked problem: `mcur` = unvisited bits of mask word `mword`, (mimg, msub) = position
+    const unsigned long long* mwords = nullptr;
+    unsigned long long mcur = 0;
+    int mword = 0, mnwords = 0, mimg = 0, msub = 0, mtpi = 1, mk0 = 0;
     if constexpr (KMAP) {
-        if (gtab && gtab[pidx].kmap) {
-            kmap = gtab[pidx].kmap;
-            nk = min(*gtab[pidx].nk_dev, nk_all);
+        if (gtab && gtab[pidx].image_mask) {
+            mwords = gtab[pidx].image_mask;
+            mtpi = gtab[pidx].tiles_per_image;
+            mnwords = (nk_all / mtpi + 63) / 64;
+            int bits = 0;
+            for (int w = 0; w < mnwords; ++w) bits += __popcll(mwords[w]);
+            nk = min(bits * mtpi, nk_all);
+            mcur = mwords[0];
+            msub = mtpi;       // "current image used up": the first call fetches the first set bit
         }
     }
+    // first row of the next K tile in staging order (tiles are staged strictly in order 0, 1, 2, ...; past the
+    // end the last tile is staged again, as the unmasked clamp does)
+    auto masked_next_k0 = [&]() {
+        if (msub == mtpi) {
+            while (mcur == 0 && mword + 1 < mnwords) mcur = mwords[++mword];
+            if (mcur != 0) {
+                mimg = mword * 64 + __builtin_ctzll(mcur);
+                mcur &= mcur - 1;
+                msub = 0;
+            } else {
+                return mk0;
+            }
+        }
+        mk0 = (mimg * mtpi + msub) * BK;
+        ++msub;
+        return mk0;
+    };
     long ydelta = 0;
     if constexpr (ROUTE) {
         const int ex = rt.expert[i0 / T3];
@@ -1013,19 +1040,24 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     auto k_loop = [&](auto rs_tag) {
         constexpr bool RS = decltype(rs_tag)::value;
         // unit 0-2 = X rows 0-63 / 64-127 / 128-191, 3-5 = Y columns likewise; K tile u lives in stage u % 3
-        auto stage = [&](int unit, int u, int st) {
-            const int kt = kt0 + (u < nk ? u : nk - 1);
-            int k0 = kt * BK;
+        int kstage = 0;   // first reduction row of the K tile being staged
+        auto pick = [&](int u) {
+            kstage = (kt0 + (u < nk ? u : nk - 1)) * BK;
             if constexpr (KMAP) {
-                if (kmap) k0 = kmap[kt];
+                if (mwords) kstage = masked_next_k0();
             }
+        };
+        auto stage = [&](int unit, int u, int st) {
+            const int k0 = kstage;
             char* dst = lds[st] + unit * UNIT_BYTES;
             if (unit < 3) stage_unit<XKMAJ>(X, i0 + unit * 64, k0, dst, wave, lane);
             else if constexpr (ROUTE) stage_unit_routed<YKMAJ>(Y, j0 + (unit - 3) * 64, k0, dst, wave, lane, rt.split, ydelta);
             else stage_unit<YKMAJ>(Y, j0 + (unit - 3) * 64, k0, dst, wave, lane);
         };
+        pick(0);
 #pragma unroll
         for (int un = 0; un < 6; ++un) stage(un, 0, 0);
+        pick(1);
 #pragma unroll
         for (int un = 0; un < 6; ++un) stage(un, 1, 1);
         VP_WAIT_VM(6);
@@ -1035,6 +1067,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         int cur = 0, nxt2 = 2;                        // stage of K tile u, of K tile u + 2
 #pragma unroll 1
         for (int u = 0; u < nk; ++u) {
+            pick(u + 2);
             const char* lx = lds[cur];
             const char* ly = lds[cur] + 3 * UNIT_BYTES;
             bf16x8 xf[3][2], yf[3][2];

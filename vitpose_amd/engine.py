@@ -222,10 +222,9 @@ class VitRunner:
 
     def route_buffers(self, ws: 'Workspace', B: int):
         """Plan-owned routing state of one batch size: expert [B] (the images' dataset indices) and, for the
-        expert weight gradients, per expert the list of 64-token K tiles of its images (kmap) and their count."""
+        expert weight gradients, per expert the bit mask of its images (64 images per int64 word)."""
         return (ws.get(f'moe_expert.{B}', (B,), torch.int32, zero=True),
-                ws.get(f'moe_kmap.{B}', (max(self.nexp, 1), 3 * B), torch.int32, zero=True),
-                ws.get(f'moe_nk.{B}', (max(self.nexp, 1),), torch.int32, zero=True))
+                ws.get(f'moe_mask.{B}', (max(self.nexp, 1), (B + 63) // 64), torch.int64, zero=True))
 
     def set_routing(self, ws: 'Workspace', B: int, dataset_source):
         """Fill the routing buffers from the per-image dataset indices (host list / array / tensor)."""
@@ -236,15 +235,12 @@ class VitRunner:
             raise ValueError(f'{src.shape[0]} dataset indices for a batch of {B} images')
         if src.min() < 0 or src.max() >= self.nexp:
             raise ValueError(f'dataset index outside [0, {self.nexp}) (num_expert)')
-        expert, kmap, nk = self.route_buffers(ws, B)
-        km = np.zeros((self.nexp, 3 * B), np.int32)
-        cnt = np.zeros(self.nexp, np.int32)
+        expert, mask = self.route_buffers(ws, B)
+        words = np.zeros((self.nexp, (B + 63) // 64), np.uint64)
         for b, e in enumerate(src):
-            km[e, cnt[e]:cnt[e] + 3] = b * self.T + np.arange(3) * 64
-            cnt[e] += 3
+            words[e, b // 64] |= np.uint64(1) << np.uint64(b % 64)
         expert.copy_(torch.from_numpy(src.astype(np.int32)))
-        kmap.copy_(torch.from_numpy(km))
-        nk.copy_(torch.from_numpy(cnt))
+        mask.copy_(torch.from_numpy(words.view(np.int64)))
 
     def _route(self, ws, B, i, with_bias=True):
         if not self.part:
@@ -420,7 +416,7 @@ class VitRunner:
         P, Ns = self.part, self.E - self.part
         if P:
             G = max(G, 1)     # the expert weight gradients exist in the grouped launch only
-            _, kmap, nk_dev = self.route_buffers(ws, B)
+            _, img_mask = self.route_buffers(ws, B)
             colsum_scratch = ws.f32('moe_colsum_scratch', E)
         slab = ws.f32('splitk_slab', _slab_elems(max(E * Hd, 3 * E * E, E * self.Kpe), M)) if G <= 0 else None
         pending = []
@@ -432,7 +428,7 @@ class VitRunner:
             xe = dxb_t.view(-1)[Ns:]
             for j in range(self.nexp):
                 pending.append((xe, h_t, self.g(b + f'mlp.experts.{j}.weight'), P, Hd, E, Hd,
-                                self.g(b + f'mlp.experts.{j}.bias'), kmap[j], nk_dev[j:j + 1]))
+                                self.g(b + f'mlp.experts.{j}.bias'), img_mask[j], self.T // 64))
 
         def fc2_bias_grad(i):
             """Target of the LayerNorm-backward column sums of the gradient that enters Block i's fc2."""

@@ -284,9 +284,10 @@ class Plan:
     def wgrad_group(self, problems, K, tile_mode=0):
         """One launch for several independent weight gradients out_i [M_i][N_i] = x_i^T y_i over a common
         reduction extent K.  problems: list of (x [K][M] bf16, y [K][N] bf16, out f32, M, N, ldx, ldy[, rowsum
-        [, kmap, nk]]); rowsum (f32 [M], optional) receives sum_k x[k][m], the bias gradient of the same Linear;
-        kmap / nk (int32 device tensors, optional): the problem reduces over the 64-row K tiles that start at rows
-        kmap[0 .. nk[0]) only (expert weight gradients: the tokens of the images routed to that expert)."""
+        [, image_mask, tiles_per_image]]); rowsum (f32 [M], optional) receives sum_k x[k][m], the bias gradient of
+        the same Linear; image_mask (int64 device tensor of ceil(images / 64) words, optional): the K rows are images
+        of tiles_per_image * 64 rows and the problem reduces over the images whose bit is set only (expert weight
+        gradients: the tokens of the images routed to that expert)."""
         from ._lib import GroupEntry
         if len(problems) > 64:               # the kernel maps a workgroup to its problem with one 64-lane ballot
             self.wgrad_group(problems[:64], K, tile_mode)
@@ -307,8 +308,10 @@ class Plan:
                     _chk(prob[7], torch.float32, 'rowsum')
                     g.rowsum = prob[7].data_ptr()
                 if len(prob) > 8 and prob[8] is not None:
-                    _chk(prob[8], torch.int32, 'kmap'), _chk(prob[9], torch.int32, 'nk')
-                    g.kmap, g.nk_dev = prob[8].data_ptr(), prob[9].data_ptr()
+                    _chk(prob[8], torch.int64, 'image_mask')
+                    if K % (64 * prob[9]) or prob[8].numel() * 64 < K // (64 * prob[9]):
+                        raise ValueError('image_mask: K must be whole images and the mask must cover them')
+                    g.image_mask, g.tiles_per_image = prob[8].data_ptr(), int(prob[9])
             total = ctypes.c_int(0)
             rc = self.L.vp_wgrad_group_table(arr, n, mode, ctypes.byref(total))
             if rc != 0:
@@ -325,10 +328,18 @@ class Plan:
                     for mode in (2, 3)})
             tile_mode = _TUNE_CACHE.get(key, 3)
         blob, total = table(tile_mode)
-        keep = [blob] + [t for p in problems for t in p[:3]] + [t for p in problems for t in p[7:]]
+        keep = [blob] + [t for p in problems for t in p[:3]] + [t for p in problems for t in p[7:9]]
         # timing tag in the (x_kmajor, y_kmajor, epilogue, M, N, K) form of gemm(): epilogue 100 = grouped,
         # M * N = summed output elements
-        self.tags[len(self.calls)] = (1, 1, 100, sum(p[3] * p[4] for p in problems), 1, K)
+        # (masked problems that share one x operand partition its K rows among them: counted once)
+        seen, mn = set(), 0
+        for p in problems:
+            if len(p) > 8 and p[8] is not None:
+                if p[0].data_ptr() in seen:
+                    continue
+                seen.add(p[0].data_ptr())
+            mn += p[3] * p[4]
+        self.tags[len(self.calls)] = (1, 1, 100, mn, 1, K)
         if mapped:
             self._add('vp_wgrad_grouped_kmap_bf16', _p(blob), n, total, K, keep=tuple(keep))
         else:
