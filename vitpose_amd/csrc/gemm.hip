@@ -1367,6 +1367,7 @@ extern "C" int vp_wgrad_group_table(vp_group_entry* problems, int count, int til
         VP_CHECK_ARG(g.x && g.y && g.out && g.M >= 8 && g.N >= 8 && g.M % 8 == 0 && g.N % 8 == 0);
         VP_CHECK_ARG(g.ldx % 8 == 0 && g.ldy % 8 == 0 && g.ldo % 4 == 0 && g.ldx >= g.M && g.ldy >= g.N && g.ldo >= g.N);
         VP_CHECK_ARG(((uintptr_t)g.x & 15) == 0 && ((uintptr_t)g.y & 15) == 0 && ((uintptr_t)g.out & 15) == 0);
+        if (g.image_mask) VP_CHECK_ARG(tile_mode == 3 && g.tiles_per_image >= 1);   // masked problems: 192-tile kernel
         g.tiles_n = (g.N + T - 1) / T;
         g.ntiles = ((g.M + T - 1) / T) * g.tiles_n;
         g.tile0 = t0;
