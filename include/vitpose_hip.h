@@ -118,7 +118,17 @@ int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, con
                      float* dcolsum, int M, int E, float* workspace, size_t workspace_floats,
                      vp_stream_t stream);
 /* workspace: caller-owned scratch for the per-workgroup partial column sums, at least 3*E floats
- * (3*E*512 floats lets the kernel use its full grid). */
+ * (3*E*512 floats lets the kernel use its full grid).
+ * Deferred column sums: with dgamma == dbeta == dcolsum == NULL the call leaves its partial sums in `workspace`
+ * ([blocks][3][E], blocks = vp_layernorm_bwd_blocks(M, E, workspace_floats)) and vp_layernorm_bwd_finalize adds
+ * the sums of several such workspaces to their targets in ONE launch (a training step has 2 * depth + 1 LayerNorm
+ * backward passes whose parameter gradients nobody reads before the optimizer or the gradient exchange).
+ * `table_dev` lives in device memory; NULL targets of an entry are skipped. */
+typedef struct vp_ln_partial {
+    const float* partial; float* dgamma; float* dbeta; float* dcolsum; int blocks; int reserved;
+} vp_ln_partial;   /* 40 bytes */
+int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats);
+int vp_layernorm_bwd_finalize(const vp_ln_partial* table_dev, int count, int E, vp_stream_t stream);
 
 /* ------------------------------------------------------------- Attention --------
  * Attention.forward core, vit.py:102-111: softmax(q k^T * scale) v over all `tokens`

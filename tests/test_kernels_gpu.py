@@ -151,6 +151,20 @@ def test_layernorm_fwd_bwd(dev, E):
     torch.testing.assert_close(dg - 1.0, gr.grad, rtol=1e-3, atol=2e-3)  # accumulates onto the 1s
     torch.testing.assert_close(db, br.grad, rtol=1e-3, atol=2e-3)
     torch.testing.assert_close(dc, scaled.sum(0), rtol=1e-3, atol=5e-3)
+    # deferred column sums: two backward passes leave their partial sums in their own workspaces, one launch
+    # adds them to the targets (NULL targets are skipped) -- the same numbers as the direct path, bit for bit
+    w1, w2 = torch.empty(3 * E * 512, device=dev), torch.empty(3 * E * 40, device=dev)
+    dg2, db2, dc2 = torch.ones(E, device=dev), torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    dg3 = torch.zeros(E, device=dev)
+    dx2 = torch.empty_like(dx)
+
+    def deferred(p):
+        p.layernorm_bwd(dy, x, mean, rstd, g, dres, dx2, dxb, rs, T, None, None, None, M, E, workspace=w1)
+        p.layernorm_bwd(dy, x, mean, rstd, g, dres, dx2, dxb, rs, T, None, None, None, M, E, workspace=w2)
+        p.ln_finalize([(w1, dg2, db2, dc2), (w2, dg3, None, None)], M, E)
+    run(deferred)
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(dc2, dc)
+    torch.testing.assert_close(dg3, gr.grad, rtol=1e-3, atol=2e-3)   # a smaller workspace: fewer, longer partial sums
 
 
 def _attn_ref(qkv, B, H, d, scale):

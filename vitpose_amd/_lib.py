@@ -45,6 +45,11 @@ class GroupEntry(Structure):
                 ('image_mask', c_void_p), ('tiles_per_image', c_int)]
 
 
+class LnPartial(Structure):
+    _fields_ = [('partial', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p), ('dcolsum', c_void_p),
+                ('blocks', c_int), ('reserved', c_int)]
+
+
 SIGNATURES = {
     'vp_gemm_bf16': [POINTER(GemmArgs), P],
     'vp_deconv_fwd_bf16': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
@@ -55,6 +60,8 @@ SIGNATURES = {
     'vp_splitk_reduce': [P, c_int, c_long, c_size_t, P, c_int, P],
     'vp_layernorm_fwd': [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, c_size_t, P],
+    'vp_layernorm_bwd_finalize': [P, c_int, c_int, P],
+    'vp_layernorm_bwd_blocks': [c_int, c_int, c_size_t],       # host-side helper: no stream argument
     'vp_attention_fwd': [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     'vp_attention_bwd': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     'vp_patch_im2col': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

@@ -227,7 +227,55 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     }
 }
 
+// the same reduction for several LayerNorm backward passes at once: blockIdx.y = entry of the table
+__global__ __launch_bounds__(256) void ln_bwd_finalize_batched_kernel(const vp_ln_partial* __restrict__ table, int E) {
+    __shared__ float red[16][17];
+    const vp_ln_partial t = table[blockIdx.y];
+    const float* partial = t.partial;
+    const int nblocks = t.blocks;
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < 3 * E) {
+        int b = ry;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += partial[(size_t)b * 3 * E + j];
+            s1 += partial[(size_t)(b + 16) * 3 * E + j];
+            s2 += partial[(size_t)(b + 32) * 3 * E + j];
+            s3 += partial[(size_t)(b + 48) * 3 * E + j];
+        }
+        for (; b < nblocks; b += 16) s0 += partial[(size_t)b * 3 * E + j];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && j < 3 * E) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += red[r][cx];
+        float* dst = j < E ? t.dgamma : (j < 2 * E ? t.dbeta : t.dcolsum);
+        if (dst) dst[j % E] += acc;
+    }
+}
+
+inline int ln_bwd_blocks(int M, int E, size_t workspace_floats) {
+    int blocks = (M + 7) / 8;
+    if (blocks > 512) blocks = 512;
+    if ((size_t)blocks * 3 * E > workspace_floats) blocks = (int)(workspace_floats / (3 * (size_t)E));
+    return blocks;
+}
+
 }  // namespace
+
+extern "C" int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats) {
+    if (M <= 0 || E <= 0) return VP_ERR_ARG;
+    return ln_bwd_blocks(M, E, workspace_floats);
+}
+
+extern "C" int vp_layernorm_bwd_finalize(const vp_ln_partial* table_dev, int count, int E, hipStream_t stream) {
+    VP_CHECK_ARG(table_dev && count > 0 && count <= 65535 && E > 0);
+    hipLaunchKernelGGL(ln_bwd_finalize_batched_kernel, dim3((3 * E + 15) / 16, count), dim3(256), 0, stream, table_dev, E);
+    VP_LAUNCH_RET();
+}
 
 extern "C" int vp_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                                 float* mean, float* rstd, int M, int E, float eps, hipStream_t stream) {
@@ -260,9 +308,7 @@ extern "C" int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float
     VP_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && (dx || dxb_bf16) && workspace);
     VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * 8);
     if (rowscale) VP_CHECK_ARG(rows_per_scale > 0);
-    int blocks = (M + 7) / 8;
-    if (blocks > 512) blocks = 512;
-    if ((size_t)blocks * 3 * E > workspace_floats) blocks = (int)(workspace_floats / (3 * (size_t)E));
+    const int blocks = ln_bwd_blocks(M, E, workspace_floats);
     VP_CHECK_ARG(blocks >= 1);
 #define VP_LNB(CH)                                                                                                \
     hipLaunchKernelGGL(ln_bwd_kernel<CH>, dim3(blocks), dim3(512), 0, stream, (const bf16*)dy_bf16, x, mean, rstd, \
@@ -278,7 +324,9 @@ extern "C" int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float
         default: VP_LNB(8); break;
     }
 #undef VP_LNB
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * E + 15) / 16), dim3(256), 0, stream, workspace, blocks, E,
-                       dgamma, dbeta, dcolsum);
+    // all three targets NULL: the partial sums stay in `workspace` for a later vp_layernorm_bwd_finalize
+    if (dgamma || dbeta || dcolsum)
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * E + 15) / 16), dim3(256), 0, stream, workspace, blocks, E,
+                           dgamma, dbeta, dcolsum);
     VP_LAUNCH_RET();
 }

@@ -86,8 +86,13 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const bf16* __restri
     // C | 2048): the per-channel coefficients stay in registers across iterations
     int cc = -1;
     float sc[8], sh[8];
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 8) % C);
+    // the 8-channel chunk of element i within its row, kept incrementally (a 64-bit modulo per iteration
+    // costs more VALU time than the iteration's memory traffic takes)
+    const unsigned cpr = (unsigned)C / 8, stride = gridDim.x * blockDim.x, cstep = stride % cpr;
+    unsigned ci = (blockIdx.x * blockDim.x + threadIdx.x) % cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride, ci += cstep) {
+        if (ci >= cpr) ci -= cpr;
+        const int c = (int)ci * 8;
         if (c != cc) {
             cc = c;
 #pragma unroll
@@ -160,8 +165,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
                                                            size_t n8, int C, float invM) {
     int cc = -1;
     float k1[8], k2[8], k3[8];
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 8) % C);
+    const unsigned cpr = (unsigned)C / 8, stride = gridDim.x * blockDim.x, cstep = stride % cpr;
+    unsigned ci = (blockIdx.x * blockDim.x + threadIdx.x) % cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride, ci += cstep) {
+        if (ci >= cpr) ci -= cpr;
+        const int c = (int)ci * 8;
         if (c != cc) {
             cc = c;
 #pragma unroll

@@ -399,7 +399,18 @@ class VitRunner:
         dx_a, dx_b = ws.f32('dx_a', M, E), ws.f32('dx_b', M, E)
         dxn = ws.bf16('dxn', M, E)
         dao = ws.bf16('dao', M, E)
-        lnws = ws.f32('ln_bwd_partials', 3 * E * 512)
+        # LayerNorm backward leaves its per-workgroup column sums (d gamma, d beta, the next bias gradient) in a
+        # workspace of its own; they are added to the gradient buffer by ONE launch per group of Blocks (with the
+        # grouped weight gradients) instead of one small launch per LayerNorm
+        ln_pending = []
+        ln_count = [0]
+
+        def ln_bwd(dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, dgamma, dbeta, dcolsum):
+            wsp = ws.f32(f'ln_bwd_partials.{ln_count[0]}', 3 * E * 512)
+            ln_count[0] += 1
+            plan.layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, T, None, None, None, M, E,
+                               workspace=wsp)
+            ln_pending.append((wsp, dgamma, dbeta, dcolsum))
         # The weight-gradient GEMMs (and the bias column sums) are off the critical path dx -> dx of the
         # backward pass: they are recorded on the plan's side stream, where they fill the CUs the
         # dependent chain leaves idle (kernel tails, HBM-bound LayerNorm / attention phases).  Their
@@ -417,7 +428,6 @@ class VitRunner:
         if P:
             G = max(G, 1)     # the expert weight gradients exist in the grouped launch only
             _, img_mask = self.route_buffers(ws, B)
-            colsum_scratch = ws.f32('moe_colsum_scratch', E)
         slab = ws.f32('splitk_slab', _slab_elems(max(E * Hd, 3 * E * E, E * self.Kpe), M)) if G <= 0 else None
         pending = []
 
@@ -432,7 +442,7 @@ class VitRunner:
 
         def fc2_bias_grad(i):
             """Target of the LayerNorm-backward column sums of the gradient that enters Block i's fc2."""
-            return colsum_scratch if P else self.g(f'blocks.{i}.mlp.fc2.bias')
+            return None if P else self.g(f'blocks.{i}.mlp.fc2.bias')   # expert routing: row sums of the grouped launch
 
         def defer(x, y, name, Mw, Nw, bias=None):
             """Weight gradient x^T y (and, with `bias`, that Linear's bias gradient = column sums of x)."""
@@ -445,6 +455,9 @@ class VitRunner:
                 pending.append((x, y, self.g(name), Mw, Nw, Mw, Nw, self.g(bias) if bias is not None else None))
 
         def flush():
+            if ln_pending:
+                plan.ln_finalize(list(ln_pending), M, E)
+                ln_pending.clear()
             if pending:
                 plan.fork()
                 with plan.on_side():
@@ -454,9 +467,9 @@ class VitRunner:
         x_last = ws.bufs[f'x_in.{self.depth}']
         dxb = dxb_buf(f'{last}.mlp')
         if self.cfg.get('last_norm', True):
-            plan.layernorm_bwd(dfeat, x_last, ws.bufs['mean_l'], ws.bufs['rstd_l'], self.w('last_norm.weight'),
-                               None, dx_a, dxb, dp_scale(last, 1), T, self.g('last_norm.weight'),
-                               self.g('last_norm.bias'), fc2_bias_grad(last), M, E, workspace=lnws)
+            ln_bwd(dfeat, x_last, ws.bufs['mean_l'], ws.bufs['rstd_l'], self.w('last_norm.weight'),
+                   None, dx_a, dxb, dp_scale(last, 1), self.g('last_norm.weight'),
+                   self.g('last_norm.bias'), fc2_bias_grad(last))
         else:
             raise NotImplementedError('last_norm=False backward')
         dx = dx_a
@@ -483,9 +496,9 @@ class VitRunner:
             plan.gemm(du, self.h(b + 'mlp.fc1.weight'), dxn, M, E, Hd, ldx=Hd, ldy=E, ldo=E, y_kmajor=True)
             # LN2 backward, residual add, scaled bf16 copy for the attention branch, proj bias grad
             dxb = dxb_buf(f'{i}.attn')
-            plan.layernorm_bwd(dxn, g['x_mid' + s], g['mean2' + s], g['rstd2' + s], self.w(b + 'norm2.weight'),
-                               dx, other, dxb, dp_scale(i, 0), T, self.g(b + 'norm2.weight'),
-                               self.g(b + 'norm2.bias'), self.g(b + 'attn.proj.bias'), M, E, workspace=lnws)
+            ln_bwd(dxn, g['x_mid' + s], g['mean2' + s], g['rstd2' + s], self.w(b + 'norm2.weight'),
+                   dx, other, dxb, dp_scale(i, 0), self.g(b + 'norm2.weight'),
+                   self.g(b + 'norm2.bias'), self.g(b + 'attn.proj.bias'))
             dx, other = other, dx
             # ---- attention branch
             plan.gemm(dxb, self.h(b + 'attn.proj.weight'), dao, M, E, E, ldx=E, ldy=E, ldo=E, y_kmajor=True)
@@ -501,9 +514,9 @@ class VitRunner:
             # the patch embedding), its column sum is that branch's fc2 bias (or the patch bias) grad
             nxt_bias = fc2_bias_grad(i - 1) if i > 0 else self.g('patch_embed.proj.bias')
             dxb = dxb_buf(f'{i - 1}.mlp' if i > 0 else 'patch')
-            plan.layernorm_bwd(dxn, g['x_in' + s], g['mean1' + s], g['rstd1' + s], self.w(b + 'norm1.weight'),
-                               dx, other, dxb, dp_scale(i - 1, 1), T, self.g(b + 'norm1.weight'),
-                               self.g(b + 'norm1.bias'), nxt_bias, M, E, workspace=lnws)
+            ln_bwd(dxn, g['x_in' + s], g['mean1' + s], g['rstd1' + s], self.w(b + 'norm1.weight'),
+                   dx, other, dxb, dp_scale(i - 1, 1), self.g(b + 'norm1.weight'),
+                   self.g(b + 'norm1.bias'), nxt_bias)
             dx, other = other, dx
             sync = after_block is not None and i > 0 and i in sync_blocks
             if i > 0 and (sync or (G > 0 and i % G == 0)):

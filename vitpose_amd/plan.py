@@ -359,6 +359,22 @@ class Plan:
                   workspace.numel(),
                   keep=(dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, dgamma, dbeta, dcolsum, workspace))
 
+    def ln_finalize(self, entries, M, E):
+        """One launch that adds the column sums several layernorm_bwd calls left in their workspaces (recorded with
+        dgamma = dbeta = dcolsum = None) to their targets.  entries: [(workspace, dgamma, dbeta, dcolsum)]."""
+        from ._lib import LnPartial
+        if not entries:
+            return
+        arr = (LnPartial * len(entries))()
+        for t, (wsp, dg, db, dc) in zip(arr, entries):
+            _chk(wsp, torch.float32, 'workspace')
+            t.partial = wsp.data_ptr()
+            t.blocks = self.L.vp_layernorm_bwd_blocks(M, E, wsp.numel())
+            t.dgamma, t.dbeta, t.dcolsum = (x.data_ptr() if x is not None else None for x in (dg, db, dc))
+        blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(entries[0][0].device)
+        self._add('vp_layernorm_bwd_finalize', _p(blob), len(entries), E,
+                  keep=(blob,) + tuple(x for e in entries for x in e))
+
     def attention_fwd(self, qkv, out, lse, B, H, d, tokens, scale):
         self._add('vp_attention_fwd', _p(qkv), _p(out), _p(lse), B, H, d, tokens, scale, keep=(qkv, out, lse))
 
