@@ -160,20 +160,26 @@ __global__ __launch_bounds__(256) void deconv_phase_im2col_kernel(const bf16* __
 // Both the data gradient (G x Wd^T) and the weight gradient (in^T x G) read it.
 __global__ __launch_bounds__(256) void deconv_out_gather16_kernel(const bf16* __restrict__ dout, bf16* __restrict__ g,
                                                                   int B, int H, int W, int C) {
-    const int chunks = (16 * C) >> 3;
-    const size_t total = (size_t)B * H * W * chunks;
+    // one wave per input pixel: the pixel's coordinates are decoded once (wave-uniform), the lanes walk its
+    // 16 * C / 8 sixteen-byte chunks with 32-bit index arithmetic
+    const unsigned chunks = (16u * (unsigned)C) >> 3, cpt = (unsigned)C >> 3;   // per pixel, per tap
+    const size_t npix = (size_t)B * H * W;
     const int Ho = 2 * H, Wo = 2 * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % chunks);
-        const size_t pix = i / chunks;
-        const int k = ch << 3, t = k / C, c = k % C;
-        const int ky = t >> 2, kx = t & 3;
-        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
-        const int oy = 2 * y - 1 + ky, ox = 2 * x - 1 + kx;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo)
-            v = *reinterpret_cast<const uint4*>(dout + (((size_t)b * Ho + oy) * Wo + ox) * C + c);
-        *reinterpret_cast<uint4*>(g + pix * (size_t)(16 * C) + k) = v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t pix = (size_t)blockIdx.x * 4 + wave; pix < npix; pix += (size_t)gridDim.x * 4) {
+        const unsigned p32 = (unsigned)(pix % ((size_t)W * H));
+        const size_t b = pix / ((size_t)W * H);
+        const int y = (int)(p32 / (unsigned)W), x = (int)(p32 % (unsigned)W);
+        const bf16* src = dout + b * (size_t)Ho * Wo * C;
+        bf16* dst = g + pix * (size_t)(16 * C);
+        for (unsigned ch = lane; ch < chunks; ch += 64) {
+            const unsigned t = ch / cpt, c = (ch - t * cpt) << 3;
+            const int oy = 2 * y - 1 + (int)(t >> 2), ox = 2 * x - 1 + (int)(t & 3);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo)
+                v = *reinterpret_cast<const uint4*>(src + ((size_t)oy * Wo + ox) * C + c);
+            *reinterpret_cast<uint4*>(dst + ((size_t)ch << 3)) = v;
+        }
     }
 }
 
