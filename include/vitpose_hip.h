@@ -215,6 +215,15 @@ int vp_deconv_fwd_bf16(const void* in_bf16, const void* wph_bf16, void* out_bf16
                        int epilogue, const float* colscale, const float* shift, const void* zero_page,
                        vp_stream_t stream);
 
+/* The data gradient of the same layer in ONE launch, the 16-tap neighbourhood of the output-grid gradient gathered
+ * on the fly (autograd of nn.ConvTranspose2d, topdown_heatmap_simple_head.py:323-332):
+ *   din[(b,iy,ix)][ci] = sum_{ky,kx,co} dout[b][2iy-1+ky][2ix-1+kx][co] * wd[ci][(ky*4+kx)*C + co],
+ * dout [B*2H*2W][C] bf16 (H, W = the layer's INPUT grid, C = its output channels), wd [Cin][16*C] bf16 (the layout
+ * vp_deconv_weight_prep writes), din [B*H*W][Cin] bf16.  relu_aux (optional, [B*H*W][Cin] bf16): the gradient is
+ * masked where relu_aux <= 0 (the ReLU in front of the layer).  C % 64 == 0, Cin % 8 == 0. */
+int vp_deconv_dgrad_bf16(const void* dout_bf16, const void* wd_bf16, void* din_bf16, int B, int H, int W, int C, int Cin,
+                         const void* relu_aux_bf16, const void* zero_page, vp_stream_t stream);
+
 /* Both compute layouts of a ConvTranspose2d(k=4) weight W [Ci][Co][4][4] (f32 master) in one pass: the phase
  * matrices wph [4][Co][4*Ci] of vp_deconv_fwd_bf16 and the 16-tap matrix wd [Ci][16*Co] the data gradient reads
  * (wd[ci][(ky*4+kx)*Co + co] = W[ci][co][ky][kx]); both bf16.  Replaces five vp_strided_cast launches per layer. */

@@ -276,6 +276,32 @@ def test_deconv_as_subpixel_gemms(dev):
     assert torch.equal(dwd.view(Ci, 16, Co).permute(0, 2, 1).reshape(Ci, Co, 4, 4), wr.grad)
 
 
+@pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 16, 12, 64, 64), (3, 16, 12, 256, 128), (1, 5, 7, 40, 64), (2, 32, 24, 768, 256)])
+def test_deconv_dgrad_implicit_16_taps(dev, B, H, W, Ci, Co):
+    """Data gradient of ConvTranspose2d(k4, s2, p1) in one launch (16-tap rows gathered by the loader): exact on
+    integer data against torch autograd, with and without the ReLU mask; partial tiles in rows and columns."""
+    x = ints((B, Ci, H, W), dev, -2, 3, seed=1)
+    wt = ints((Ci, Co, 4, 4), dev, -1, 2, seed=2)
+    dout = ints((B, Co, 2 * H, 2 * W), dev, -1, 2, seed=3)
+    xr = x.clone().requires_grad_()
+    torch.nn.functional.conv_transpose2d(xr, wt, stride=2, padding=1).backward(dout)
+    ref = xr.grad.permute(0, 2, 3, 1).reshape(B * H * W, Ci)
+    dcl = dout.permute(0, 2, 3, 1).contiguous().bfloat16().view(-1, Co)
+    wd = torch.empty(Ci, 16 * Co, device=dev, dtype=torch.bfloat16)
+    aux = ints((B * H * W, Ci), dev, -2, 3, seed=4).bfloat16()
+    dx = torch.full((B * H * W, Ci), float('nan'), device=dev, dtype=torch.bfloat16)
+    dxm = torch.full_like(dx, float('nan'))
+
+    def bwd(p):
+        p.strided_cast(wt, wd, (Ci, 16, Co, 1), (Co * 16, 1, 16, 0))
+        p.deconv_dgrad(dcl, wd, dx, B, H, W, Co, Ci)
+        p.deconv_dgrad(dcl, wd, dxm, B, H, W, Co, Ci, relu_aux=aux)
+    run(bwd)
+    assert ref.abs().max() < 256                       # integers that bf16 holds exactly
+    assert torch.equal(dx.float(), ref)
+    assert torch.equal(dxm.float(), ref * (aux.float() > 0))
+
+
 @pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 16, 12, 64, 64), (3, 16, 12, 128, 256), (1, 5, 7, 64, 40)])
 def test_deconv_fwd_fused_implicit_im2col(dev, B, H, W, Ci, Co):
     """ConvTranspose2d(k4, s2, p1) forward in one launch (four parities, gathered X operand): exact on

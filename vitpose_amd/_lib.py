@@ -54,6 +54,7 @@ SIGNATURES = {
     'vp_gemm_bf16': [POINTER(GemmArgs), P],
     'vp_deconv_fwd_bf16': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     'vp_deconv_weight_prep': [P, P, P, c_int, c_int, P],
+    'vp_deconv_dgrad_bf16': [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
     'vp_wgrad_group_table': [POINTER(GroupEntry), c_int, c_int, POINTER(c_int)],
     'vp_wgrad_grouped_bf16': [P, c_int, c_int, c_int, c_int, P],
     'vp_wgrad_grouped_kmap_bf16': [P, c_int, c_int, c_int, P],

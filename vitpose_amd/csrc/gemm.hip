@@ -468,9 +468,14 @@ constexpr int W_XBYTES = W_BM * BK * 2, W_YBYTES = W_BN * BK * 2;   // 24 KiB + 
 //   dy(0, {0, 1}) = {0, -1}, dy(1, {0, 1}) = {+1, 0}
 // and is never written to memory: the LDS-DMA source address of a tile row is the shifted pixel's channel
 // vector, or a page of zeros.  A 64-wide K step lies inside one tap (C % 64 == 0).
+//
+// taps16 (the data gradient of the same layer): rows are INPUT pixels of the H x W grid and
+//   X[(b, iy, ix)][(ky * 4 + kx) * C + c] = dout[b][2 iy - 1 + ky][2 ix - 1 + kx][c]   (0 outside the 2H x 2W grid),
+// the 16-tap neighbourhood of the OUTPUT-grid gradient that pixel (iy, ix) fed; one launch, no parities.
 struct Gather {
     int H, W, C;
     const bf16* zero;   // >= 128 bytes of zeros
+    int taps16;
 };
 
 struct GatherRows {      // per lane: the 6 tile rows it fetches (one per LDS-DMA round)
@@ -488,6 +493,17 @@ __device__ __forceinline__ GatherRows gather_rows(const Gather& g, int r0, int r
         row = row < rows ? row : rows - 1;
         const int x = row % g.W, y = (row / g.W) % g.H;
         int ok = 0;
+        if (g.taps16) {
+            const int b = row / (g.W * g.H);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int oy = 2 * y - 1 + (t >> 2), ox = 2 * x - 1 + (t & 3);
+                ok |= (oy >= 0 && oy < 2 * g.H && ox >= 0 && ox < 2 * g.W) << t;
+            }
+            gr.pix[i] = (b * 2 * g.H + 2 * y) * 2 * g.W + 2 * x;     // output-grid pixel (2 iy, 2 ix)
+            gr.ok[i] = ok;
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ty = t >> 1, tx = t & 1;
@@ -504,7 +520,8 @@ __device__ __forceinline__ void stage_tile_gather(const bf16* in, const Gather& 
                                                   int py, int px, char* lds, int wave, int lane) {
     const int t = k0 / g.C, c0 = k0 - t * g.C;            // wave-uniform
     const int ty = t >> 1, tx = t & 1;
-    const int shift = (py ? 1 - ty : -ty) * g.W + (px ? 1 - tx : -tx);
+    const int shift = g.taps16 ? ((t >> 2) - 1) * 2 * g.W + ((t & 3) - 1)
+                               : (py ? 1 - ty : -ty) * g.W + (px ? 1 - tx : -tx);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int base = (i * 4 + wave) * 64, L = base + lane;
@@ -539,13 +556,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand
     int py = 0, px = 0;
     GatherRows gr;
     if constexpr (GATHER) {
-        py = blockIdx.y >> 1;
-        px = blockIdx.y & 1;
-        Y.p += (size_t)blockIdx.y * Y.rows * Y.ld;
-        e.row_div = gth.W;
-        e.row_hi = 4 * gth.W;
-        e.row_lo = 2;
-        e.row_off = py * 2 * gth.W + px;
+        if (!gth.taps16) {
+            py = blockIdx.y >> 1;
+            px = blockIdx.y & 1;
+            Y.p += (size_t)blockIdx.y * Y.rows * Y.ld;
+            e.row_div = gth.W;
+            e.row_hi = 4 * gth.W;
+            e.row_lo = 2;
+            e.row_off = py * 2 * gth.W + px;
+        }
         gr = gather_rows(gth, i0, M, py, px, wave, lane);
     }
     auto stage_x = [&](int k0, char* dst) {
@@ -1393,6 +1412,31 @@ extern "C" int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count,
     VP_LAUNCH_RET();
 }
 
+extern "C" int vp_deconv_dgrad_bf16(const void* dout, const void* wd, void* din, int B, int H, int W, int C, int Cin,
+                                    const void* relu_aux, const void* zero_page, hipStream_t stream) {
+    VP_CHECK_ARG(dout && wd && din && zero_page && B > 0 && H > 0 && W > 0);
+    VP_CHECK_ARG(C % 64 == 0 && Cin % 8 == 0);
+    VP_CHECK_ARG(((uintptr_t)dout & 15) == 0 && ((uintptr_t)wd & 15) == 0 && ((uintptr_t)din & 15) == 0);
+    VP_CHECK_ARG((size_t)B * 4 * H * W < (size_t)0x7fffffff / 2);      // pixel indices are 32-bit
+    const int M = B * H * W, K = 16 * C;
+    Operand X{(const bf16*)dout, C, M}, Y{(const bf16*)wd, K, Cin};
+    Epi e{};
+    e.kind = relu_aux ? VP_EPI_DRELU : VP_EPI_BF16;
+    e.out = din;
+    e.ldo = Cin;
+    e.aux = relu_aux;
+    e.ldaux = Cin;
+    Gather g{H, W, C, (const bf16*)zero_page, 1};
+    const int tm = (M + W_BM - 1) / W_BM, tn = (Cin + W_BN - 1) / W_BN;
+    if (relu_aux)
+        hipLaunchKernelGGL((gemm_w2_kernel<false, VP_EPI_DRELU, true>), dim3(tm * tn), dim3(NTHREADS), 0, stream, X, Y, M,
+                           Cin, K, tn, tm * tn, e, g);
+    else
+        hipLaunchKernelGGL((gemm_w2_kernel<false, VP_EPI_BF16, true>), dim3(tm * tn), dim3(NTHREADS), 0, stream, X, Y, M,
+                           Cin, K, tn, tm * tn, e, g);
+    VP_LAUNCH_RET();
+}
+
 extern "C" int vp_wgrad_grouped_kmap_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K,
                                           hipStream_t stream) {
     VP_CHECK_ARG(table_dev && count > 0 && count <= 64 && total_tiles > 0 && K > 0 && K % BK == 0);
@@ -1419,7 +1463,7 @@ extern "C" int vp_deconv_fwd_bf16(const void* in, const void* wph, void* out, in
     e.ldo = Cout;
     e.bias = shift;
     e.colscale = colscale;
-    Gather g{H, W, C, (const bf16*)zero_page};
+    Gather g{H, W, C, (const bf16*)zero_page, 0};
     const int tm = (M + W_BM - 1) / W_BM, tn = (Cout + W_BN - 1) / W_BN;
     dim3 grid(tm * tn, 4);
     if (epilogue == VP_EPI_BF16)

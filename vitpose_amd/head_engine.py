@@ -397,7 +397,11 @@ class HeadRunner:
             plan.host(wgrad)
             # data gradient wrt the layer input: G Wd^T  (+ ReLU mask of the previous activation)
             gin = ws.bf16('hg_in' if l % 2 else 'hg_in2', Min, ci)
-            if l > 0:
+            if co % 64 == 0 and FUSED_DECONV:
+                # implicit GEMM: the 16-tap rows are gathered from dz by the loader (G is only read by the
+                # weight gradient above)
+                plan.deconv_dgrad(dz, self.wd[l], gin, B, Hi, Wi, co, ci, relu_aux=a_in if l > 0 else None)
+            elif l > 0:
                 plan.gemm(G, self.wd[l], gin, Min, ci, 16 * co, ldx=16 * co, ldy=16 * co, ldo=ci,
                           epilogue=_lib.VP_EPI_DRELU, aux=a_in, ldaux=ci)
             else:

@@ -434,6 +434,11 @@ class Plan:
         self._add('vp_deconv_fwd_bf16', _p(src), _p(wph), _p(out), B, H, W, C, Cout, epilogue, _p(colscale), _p(shift),
                   _p(zero), keep=(src, wph, out, colscale, shift, zero))
 
+    def deconv_dgrad(self, dout, wd, din, B, H, W, C, Cin, relu_aux=None):
+        zero = _zero_page(dout.device)
+        self._add('vp_deconv_dgrad_bf16', _p(dout), _p(wd), _p(din), B, H, W, C, Cin, _p(relu_aux), _p(zero),
+                  keep=(dout, wd, din, relu_aux, zero))
+
     def deconv_weight_prep(self, w, wph, wd, Ci, Co):
         _chk(w, torch.float32, 'w')
         self._add('vp_deconv_weight_prep', _p(w), _p(wph), _p(wd), Ci, Co, keep=(w, wph, wd))
