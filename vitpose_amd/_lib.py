@@ -10,6 +10,7 @@ import torch  # noqa: F401  (first: the library must bind to the HIP runtime tor
 from ctypes import POINTER, Structure, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2   # VP_ABI_VERSION of include/vitpose_hip.h this binding was written for
 LIB_PATH = os.environ.get('VITPOSE_HIP_LIB') or os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
 
 VP_EPI_BF16, VP_EPI_GELU, VP_EPI_RESID_F32, VP_EPI_DGELU = 0, 1, 2, 3
@@ -111,6 +112,8 @@ def lib():
             '`python -c "import __graft_entry__ as g; g.build()"`). There is no CPU fallback.')
     L = ctypes.CDLL(LIB_PATH)
     L.vp_abi_version.restype = c_int
+    if L.vp_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'{LIB_PATH} has ABI version {L.vp_abi_version()}, this binding needs {ABI_VERSION}: rebuild it')
     L.vp_build_arch.restype = ctypes.c_char_p
     for name, argtypes in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is not exported
