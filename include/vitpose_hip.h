@@ -92,6 +92,12 @@ typedef struct vp_gemm_args {
      * route_bias_delta[expert] floats further on.  All three arrays live on the device.  Uses the 192 x 192 tile
      * schedule; route_split % 48 == 0, k-contiguous x, no K split. */
     const int* route_expert; const long* route_delta; const long* route_bias_delta; int route_split;
+    /* optional (gather16_C > 0): the Y operand is the reduction-major 16-tap gather of `y`, never materialised --
+     * the weight gradient of ConvTranspose2d(k=4, s=2, p=1) (autograd of topdown_heatmap_simple_head.py:323-332):
+     * y = dout [B*2H*2W][C] bf16 (H, W = gather16_H / _W = the layer's INPUT grid, C = gather16_C its output
+     * channels), Y[(b,iy,ix)][(ky*4+kx)*C + c] = dout[b][2iy-1+ky][2ix-1+kx][c] (0 outside; gather16_zero: >= 128
+     * bytes of zeros on the device), K = B*H*W, N = 16*C, x_kmajor = y_kmajor = 1, VP_EPI_SPLITK_F32, C % 128 == 0. */
+    int gather16_H, gather16_W, gather16_C; const void* gather16_zero;
 } vp_gemm_args;
 
 int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);

@@ -302,6 +302,32 @@ def test_deconv_dgrad_implicit_16_taps(dev, B, H, W, Ci, Co):
     assert torch.equal(dxm.float(), ref * (aux.float() > 0))
 
 
+@pytest.mark.parametrize('B,H,W,Ci,Co,sk', [(2, 16, 12, 64, 128, 1), (3, 16, 12, 256, 128, 4), (2, 32, 24, 768, 256, 5),
+                                             (1, 32, 24, 72, 128, 12), (5, 16, 12, 264, 256, 7)])
+def test_deconv_wgrad_implicit_16_taps(dev, B, H, W, Ci, Co, sk):
+    """Weight gradient of ConvTranspose2d(k4, s2, p1) with the reduction-major 16-tap operand gathered by the
+    loader (never materialised): exact on integer data against torch autograd; several K slices (each starts its
+    pixel walk in the middle of an image), partial row tiles."""
+    from vitpose_amd import _lib
+    x = ints((B, Ci, H, W), dev, -2, 3, seed=1)
+    wt = ints((Ci, Co, 4, 4), dev, -1, 2, seed=2)
+    dout = ints((B, Co, 2 * H, 2 * W), dev, -1, 2, seed=3)
+    wr = wt.clone().requires_grad_()
+    torch.nn.functional.conv_transpose2d(x, wr, stride=2, padding=1).backward(dout)
+    xcl = x.permute(0, 2, 3, 1).contiguous().bfloat16().view(B * H * W, Ci)
+    dcl = dout.permute(0, 2, 3, 1).contiguous().bfloat16().view(-1, Co)
+    K = B * H * W
+    slab = torch.full((sk * Ci * 16 * Co,), float('nan'), device=dev)
+    dwd = torch.full((Ci, 16 * Co), float('nan'), device=dev)
+
+    def bwd(p):
+        p.gemm(xcl, dcl, slab, Ci, 16 * Co, K, ldx=Ci, ldy=Co, ldo=16 * Co, x_kmajor=True, y_kmajor=True,
+               epilogue=_lib.VP_EPI_SPLITK_F32, split_k=sk, split_stride=Ci * 16 * Co, gather16=(H, W, Co))
+        p._add('vp_splitk_reduce', slab.data_ptr(), sk, Ci * 16 * Co, Ci * 16 * Co, dwd.data_ptr(), 0)
+    run(bwd)
+    assert torch.equal(dwd.view(Ci, 16, Co).permute(0, 2, 1).reshape(Ci, Co, 4, 4), wr.grad)
+
+
 @pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 16, 12, 64, 64), (3, 16, 12, 128, 256), (1, 5, 7, 64, 40)])
 def test_deconv_fwd_fused_implicit_im2col(dev, B, H, W, Ci, Co):
     """ConvTranspose2d(k4, s2, p1) forward in one launch (four parities, gathered X operand): exact on

@@ -34,6 +34,7 @@ class GemmArgs(Structure):
         ('out_row_div', c_int), ('out_row_hi', c_int), ('out_row_lo', c_int), ('out_row_off', c_int),
         ('tail_ws', c_void_p), ('tail_ws_bytes', c_size_t), ('tail_force', c_int), ('tile_mode', c_int),
         ('route_expert', c_void_p), ('route_delta', c_void_p), ('route_bias_delta', c_void_p), ('route_split', c_int),
+        ('gather16_H', c_int), ('gather16_W', c_int), ('gather16_C', c_int), ('gather16_zero', c_void_p),
     ]
 
 

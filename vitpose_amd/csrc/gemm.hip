@@ -703,10 +703,66 @@ __device__ __forceinline__ void store_rowsum(float* rowsum, const f32x4 (&racc)[
 }
 
 
-template <bool XKMAJ, bool YKMAJ, int EPI>
+// Reduction-major 16-tap gather of a transposed conv's output-grid gradient (the Y operand of that layer's weight
+// gradient, never materialised): Y[(b, iy, ix)][(ky * 4 + kx) * C + c] = dout[b][2 iy - 1 + ky][2 ix - 1 + kx][c].
+// A lane stages the same two reduction rows (input pixels) of every K tile; their (b, y, x) are decoded once and
+// advanced by 64 pixels per K tile with adds and compares.
+struct GatherY {
+    int b[2], y[2], x[2];
+    int u;      // K tile (relative to the slice) the coordinates belong to
+};
+
+__device__ __forceinline__ void gather_y_init(GatherY& st, const Gather& g, int pix0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kr = ((i * 8 + wave) * 64 + lane) >> 4;
+        const int p = pix0 + kr, hw = g.H * g.W;
+        st.b[i] = p / hw;
+        const int r = p - st.b[i] * hw;
+        st.y[i] = r / g.W;
+        st.x[i] = r - st.y[i] * g.W;
+    }
+    st.u = 0;
+}
+
+__device__ __forceinline__ void gather_y_advance(GatherY& st, const Gather& g) {
+    const int dy = BK / g.W, dx = BK - dy * g.W;      // 64 pixels further on (host: dy + 1 <= H)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        st.x[i] += dx;
+        if (st.x[i] >= g.W) { st.x[i] -= g.W; st.y[i] += 1; }
+        st.y[i] += dy;
+        if (st.y[i] >= g.H) { st.y[i] -= g.H; st.b[i] += 1; }
+    }
+    ++st.u;
+}
+
+// one 128-column half tile (inside ONE tap: C % 128 == 0) of the gathered operand, image layout of stage_half<true>
+__device__ __forceinline__ void stage_half_gather_y(const bf16* dout, const Gather& g, const GatherY& st, int col0,
+                                                    char* lds, int wave, int lane) {
+    const int t = col0 / g.C, cbase = col0 - t * g.C;   // wave-uniform
+    const int ky = t >> 2, kx = t & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int base = (i * 8 + wave) * 64;
+        const int L = base + lane;
+        const int kr = L >> 4, s16 = L & 15;
+        const int unit = (s16 >> 1) ^ kmaj_key(kr);
+        const int cc = (unit * 2 + (s16 & 1)) * 8;
+        const int oy = 2 * st.y[i] - 1 + ky, ox = 2 * st.x[i] - 1 + kx;
+        const bool ok = oy >= 0 && oy < 2 * g.H && ox >= 0 && ox < 2 * g.W;
+        const bf16* src = ok ? dout + (((size_t)st.b[i] * 2 * g.H + oy) * 2 * g.W + ox) * g.C + cbase + cc
+                             : g.zero + (cc & 56);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
+    }
+}
+
+template <bool XKMAJ, bool YKMAJ, int EPI, bool GY = false>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Operand Y, int M, int N, int K,
                                                                 int tiles_n, int ntiles, int ksplit_tiles, Epi e,
-                                                                const vp_group_entry* gtab, int ngtab) {
+                                                                const vp_group_entry* gtab, int ngtab,
+                                                                Gather gth = Gather{}) {
     __shared__ __attribute__((aligned(16))) char lds[2][4][HALF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -747,11 +803,24 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
     auto k_loop = [&](auto rs_tag) {
         constexpr bool RS = decltype(rs_tag)::value;
         // slot 0/1 = X halves, 2/3 = Y halves; K tile u (relative) lives in stage u & 1
+        GatherY gy[2];
+        if constexpr (GY) {
+            gather_y_init(gy[0], gth, kt0 * BK, wave, lane);
+            gy[1] = gy[0];
+        }
         auto stage = [&](int slot, int u) {
-            const int k0 = (kt0 + (u < nk ? u : nk - 1)) * BK;
+            const int uu = u < nk ? u : nk - 1;
+            const int k0 = (kt0 + uu) * BK;
             char* dst = lds[u & 1][slot];
-            if (slot < 2) stage_half<XKMAJ>(X, i0 + slot * 128, k0, dst, wave, lane);
-            else stage_half<YKMAJ>(Y, j0 + (slot - 2) * 128, k0, dst, wave, lane);
+            if (slot < 2) {
+                stage_half<XKMAJ>(X, i0 + slot * 128, k0, dst, wave, lane);
+            } else if constexpr (GY) {
+                GatherY& st = gy[slot - 2];              // each Y half walks the K tiles in order
+                if (st.u < uu) gather_y_advance(st, gth);
+                stage_half_gather_y(Y.p, gth, st, j0 + (slot - 2) * 128, dst, wave, lane);
+            } else {
+                stage_half<YKMAJ>(Y, j0 + (slot - 2) * 128, k0, dst, wave, lane);
+            }
         };
         stage(0, 0);
         stage(1, 0);
@@ -1258,6 +1327,19 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
         }
         VP_LAUNCH_RET();
     }
+    if (a->gather16_C > 0) {
+        // Y = reduction-major 16-tap gather of a->y (the deconv weight gradient): 256 x 256 tiles, split-K slabs
+        if constexpr (XK && YK) {
+            if (a->epilogue != VP_EPI_SPLITK_F32) return VP_ERR_UNSUPPORTED;
+            const int tm2 = (a->M + T2 - 1) / T2, tn2 = (a->N + T2 - 1) / T2, nt2 = tm2 * tn2;
+            Gather g{a->gather16_H, a->gather16_W, a->gather16_C, (const bf16*)a->gather16_zero, 1};
+            hipLaunchKernelGGL((gemm256_kernel<true, true, VP_EPI_SPLITK_F32, true>), dim3(nt2 * split), dim3(T2_THREADS),
+                               0, st, X, Y, a->M, a->N, a->K, tn2, nt2, ksplit_tiles, e, nullptr, 0, g);
+            VP_LAUNCH_RET();
+        } else {
+            return VP_ERR_UNSUPPORTED;
+        }
+    }
     if (a->route_expert) {
         // per-image expert routing: 192-row tiles (one image each), forward / data-gradient products
         if (XK || split > 1 || a->M % T3 != 0 || a->route_split % 48 != 0 || !a->route_delta) return VP_ERR_UNSUPPORTED;
@@ -1371,6 +1453,12 @@ extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
     if (a->rowscale) VP_CHECK_ARG(a->rows_per_scale > 0);
     if (a->pos) VP_CHECK_ARG(a->pos_rows > 0);
     if (a->route_expert) VP_CHECK_ARG(a->route_delta && a->route_split >= 0 && !a->x_kmajor);
+    if (a->gather16_C > 0) {
+        const int H = a->gather16_H, W = a->gather16_W, C = a->gather16_C;
+        VP_CHECK_ARG(a->gather16_zero && H > 0 && W > 0 && W <= BK && C % 128 == 0 && a->N == 16 * C);
+        VP_CHECK_ARG(a->K % (H * W) == 0 && BK / W + 1 <= H);             // whole images; one row wrap per K tile
+        VP_CHECK_ARG((size_t)a->K * 4 < (size_t)0x7fffffff);               // pixel indices are 32-bit
+    }
     if (a->x_kmajor) return a->y_kmajor ? launch_layout<true, true>(a, stream) : launch_layout<true, false>(a, stream);
     return a->y_kmajor ? launch_layout<false, true>(a, stream) : launch_layout<false, false>(a, stream);
 }

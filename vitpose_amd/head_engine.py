@@ -19,6 +19,8 @@ from .engine import ParamStore, Workspace, _slab_elems, _split_k
 from .plan import Plan
 
 FUSED_DECONV = os.environ.get('VITPOSE_FUSED_DECONV', '1') != '0'   # 0: explicit im2col + one GEMM per parity
+# VITPOSE_DECONV_WGRAD_GATHER=0: materialise the 16-tap matrix for the deconv weight gradients instead of gathering it in the GEMM loader
+WGRAD_GATHER = os.environ.get('VITPOSE_DECONV_WGRAD_GATHER', '1') != '0'
 KPAD = 64  # heat-map channels (17 COCO ... 133 COCO-WholeBody) are padded to whole 64-wide MFMA K steps
 
 
@@ -383,12 +385,17 @@ class HeadRunner:
             dz = ws.bf16('hdz', Mout, co)
             plan.bn_bwd(g, ws.bufs[f'z.{l}'], self.bn_mean[l], self.bn_invstd[l], self.w(bn + 'weight'),
                         self.g(bn + 'weight'), self.g(bn + 'bias'), dz, Mout, co)
-            G = ws.bf16('hG', Min * 16 * co)
-            plan.deconv_out_gather16(dz, G, B, Hi, Wi, co)
             a_in = ws.bufs[f'a.{l - 1}'] if l > 0 else feat
-            # dWd [ci][16co] = a_in^T G
-            plan.wgrad(a_in, G, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=16 * co,
-                       split_k=_split_k(ci, 16 * co, Min), slab=slab)
+            implicit = co % 128 == 0 and FUSED_DECONV and WGRAD_GATHER and Wi <= 64 and 64 // Wi + 1 <= Hi and Min % 64 == 0
+            if implicit:
+                # dWd [ci][16co] = a_in^T G with G, the 16-tap gather of dz, read through the loader (never stored)
+                plan.wgrad(a_in, dz, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=co,
+                           split_k=_split_k(ci, 16 * co, Min), slab=slab, gather16=(Hi, Wi, co))
+            else:
+                G = ws.bf16('hG', Min * 16 * co)
+                plan.deconv_out_gather16(dz, G, B, Hi, Wi, co)
+                plan.wgrad(a_in, G, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=16 * co,
+                           split_k=_split_k(ci, 16 * co, Min), slab=slab)
             gw, dwd = self.g(f'deconv_layers.{3 * l}.weight'), self.dwd[l]
 
             def wgrad(gw=gw, dwd=dwd, ci=ci, co=co):

@@ -199,10 +199,18 @@ class Plan:
     def gemm(self, x, y, out, M, N, K, *, ldx, ldy, ldo, x_kmajor=False, y_kmajor=False,
              epilogue=_lib.VP_EPI_BF16, out2=None, bias=None, colscale=None, resid=None,
              rowscale=None, rows_per_scale=0, aux=None, ldaux=0, pos=None, pos_rows=0, split_k=1,
-             row_map=None, split_stride=0, tail_force=False, tile_mode=0, route=None):
-        """route = (expert [images] int32, delta [experts] int64, bias_delta [experts] int64 or None, split):
+             row_map=None, split_stride=0, tail_force=False, tile_mode=0, route=None, gather16=None):
+        """gather16 = (H, W, C): y is a transposed conv's output-grid gradient [B*2H*2W][C] and the Y operand its
+        reduction-major 16-tap gather (see vp_gemm_args in the header).
+        route = (expert [images] int32, delta [experts] int64, bias_delta [experts] int64 or None, split):
         per-image routing of the Y operand (mixture-of-experts FFN; see vp_gemm_args in the header)."""
         a = GemmArgs()
+        if gather16 is not None:
+            zero = _zero_page(out.device)
+            a.gather16_H, a.gather16_W, a.gather16_C = gather16
+            a.gather16_zero = zero.data_ptr()
+            self.keep.append(zero)
+            tile_mode = 2
         if route is not None:
             r_exp, r_delta, r_bdelta, r_split = route
             _chk(r_exp, torch.int32, 'route expert'), _chk(r_delta, torch.int64, 'route delta')
@@ -247,15 +255,19 @@ class Plan:
         self._add('vp_gemm_bf16', ctypes.byref(a),
                   keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
 
-    def wgrad(self, x, y, out, M, N, K, *, ldx, ldy, split_k, slab, accumulate=False, tile_mode=0):
+    def wgrad(self, x, y, out, M, N, K, *, ldx, ldy, split_k, slab, accumulate=False, tile_mode=0, gather16=None):
         """out[M][N] (f32) (+)= x^T y with x [K][M], y [K][N] (both reduction-major): the weight
         gradient of a Linear / conv-as-GEMM.  The reduction over K (= tokens) is cut into
         `split_k` slices that write f32 slabs, summed by vp_splitk_reduce (deterministic)."""
-        if split_k <= 1 and not accumulate:
+        if split_k <= 1 and not accumulate and gather16 is None:
             return self.gemm(x, y, out, M, N, K, ldx=ldx, ldy=ldy, ldo=N, x_kmajor=True, y_kmajor=True,
                              epilogue=_lib.VP_EPI_F32, tile_mode=tile_mode)
         split_k = max(1, min(split_k, K // 64))
-        if AUTOTUNE and tile_mode == 0 and M >= 256 and N >= 256 and K >= 1024:
+        if gather16 is not None:
+            # the gathered operand exists in the 256 x 256 kernel (one workgroup per CU): K slices for one round of the chip
+            t256 = ((M + 255) // 256) * ((N + 255) // 256)
+            tile_mode, split_k = 2, max(1, min(K // 64, 256 // t256, slab.numel() // (M * N)))
+        elif AUTOTUNE and tile_mode == 0 and M >= 256 and N >= 256 and K >= 1024:
             key = ('wgrad', M, N, K, str(out.device))
             if key not in _TUNE_CACHE:
                 nk = K // 64
@@ -278,7 +290,8 @@ class Plan:
             tile_mode, split_k = _TUNE_CACHE[key]
         assert slab.numel() >= split_k * M * N
         self.gemm(x, y, slab, M, N, K, ldx=ldx, ldy=ldy, ldo=N, x_kmajor=True, y_kmajor=True,
-                  epilogue=_lib.VP_EPI_SPLITK_F32, split_k=split_k, split_stride=M * N, tile_mode=tile_mode)
+                  epilogue=_lib.VP_EPI_SPLITK_F32, split_k=split_k, split_stride=M * N, tile_mode=tile_mode,
+                  gather16=gather16)
         self._add('vp_splitk_reduce', _p(slab), split_k, M * N, M * N, _p(out), int(accumulate), keep=(slab, out))
 
     def wgrad_group(self, problems, K, tile_mode=0):
