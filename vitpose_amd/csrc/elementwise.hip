@@ -188,7 +188,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             size_t n4, float* __restrict__ out, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(out + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * stride + i * 4);
+        // four slabs in flight per step (a load that the next add waits for costs a full memory latency)
+        int z = 0;
+        for (; z + 4 <= nsplit; z += 4) {
+            const float* q = slab + (size_t)z * stride + i * 4;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(q), a1 = *reinterpret_cast<const f32x4*>(q + stride);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(q + 2 * stride);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(q + 3 * stride);
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(slab + (size_t)z * stride + i * 4);
         *reinterpret_cast<f32x4*>(out + i * 4) = s;
     }
 }
