@@ -130,7 +130,14 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) s += *reinterpret_cast<const f32x4*>(x + (size_t)b * n + i);
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {           // eight images in flight (few workgroups: latency-, not bandwidth-bound)
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + (size_t)(b + j) * n + i);
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; b < B; ++b) s += *reinterpret_cast<const f32x4*>(x + (size_t)b * n + i);
     *reinterpret_cast<f32x4*>(out + i) = s;
 }
 

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ 
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (col < C) {
         const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+#pragma unroll 4
         for (int r = r0 + ry; r < r1; r += 8) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(z + (size_t)r * C + col);
 #pragma unroll
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restri
             is[j] = invstd[col + j];
         }
         const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+#pragma unroll 4
         for (int r = r0 + ry; r < r1; r += 8) {
             const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + (size_t)r * C + col);
             const bf16x8 zv = *reinterpret_cast<const bf16x8*>(z + (size_t)r * C + col);
