@@ -116,9 +116,31 @@ struct Epi {
 #define VP_ST_OK(c) (c)
 #endif
 
+// The addend of the VP_EPI_RESID_F32 epilogue (residual row, else position row, else 0) of one wave's block, in the
+// register layout of its accumulators: loaded BEFORE the K loop by kernels that own one output tile per CU, so that
+// after the loop only the store half of the epilogue's HBM traffic is left.
+template <int FM, int FN>
+__device__ __forceinline__ void load_addend(const Epi& e, f32x4 (&pre)[FM][FN], int row0, int col0, int lane, int M,
+                                            int N) {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+        const int row_raw = row0 + a * 16 + li;
+        const int row = row_raw < M ? row_raw : M - 1;
+        const float* add = e.resid ? e.resid + (size_t)row * e.ldo
+                                   : (e.pos ? e.pos + (size_t)(row % e.pos_rows) * e.ldo : nullptr);
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int c = col0 + b * 16 + g * 4;
+            const int col = c + 3 < N ? c : N - 4;
+            pre[a][b] = add ? *reinterpret_cast<const f32x4*>(add + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 template <int EPI, int FM, int FN>
 __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
-                                             int M, int N, int slice = 0) {
+                                             int M, int N, int slice = 0, const f32x4 (*pre)[FN] = nullptr) {
     const int g = lane >> 4, li = lane & 15;
     int col[FN];
     bool cok[FN];
@@ -177,8 +199,10 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
             float* o = (float*)e.out + orow * e.ldo;
             f32x4 ad[FN];
 #pragma unroll
-            for (int b = 0; b < FN; ++b)
-                ad[b] = add ? *reinterpret_cast<const f32x4*>(add + col[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < FN; ++b) {
+                if (pre) ad[b] = pre[a][b];
+                else ad[b] = add ? *reinterpret_cast<const f32x4*>(add + col[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
                 const f32x4 v = ad[b] + (acc[a][b] + bias[b]) * rs;
@@ -1116,6 +1140,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // residual / position addend of this wave's block: in flight under the whole K loop
+    f32x4 pre[EPI == VP_EPI_RESID_F32 ? 6 : 1][3];
+    if constexpr (EPI == VP_EPI_RESID_F32) load_addend<6, 3>(e, pre, i0 + grp * 96, j0 + wc * 48, lane, M, N);
     constexpr bool ROWSUM = XKMAJ && YKMAJ && EPI == VP_EPI_F32;
     const bool do_rs = ROWSUM && rowsum != nullptr && j0 == 0;   // workgroup-uniform; fragment a goes to wave a % 4
     f32x4 racc[ROWSUM ? 6 : 1];
@@ -1248,7 +1275,10 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     if constexpr (ROWSUM) {
         if (do_rs) store_rowsum<6>(rowsum, racc, i0 + grp * 96, lane, M, wc);
     }
-    run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice);
+    if constexpr (EPI == VP_EPI_RESID_F32)
+        run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice, pre);
+    else
+        run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice);
 }
 
 inline int num_cus() {
