@@ -371,3 +371,43 @@ def test_wholebody_133_keypoints_train_step_and_eval(dev):
     ev = make_engine(TOY, hc, bb, hd, dev)      # fresh BatchNorm running statistics (the train step moved eng's)
     assert relerr(ev.infer(img.to(dev)), ref_eval)[0] < 3e-2
     assert (ev.infer(img.to(dev), exact=True).cpu() - ref_eval).abs().max().item() < 1e-3 * max(1.0, ref_eval.abs().max().item())
+
+
+@pytest.mark.parametrize('B', [1, 3, 7])
+def test_odd_batch_sizes_train_and_eval_vs_oracle(dev, B):
+    """Ragged batches (1, 3, 7 images: partial GEMM tiles in every product, BatchNorm statistics over a single image
+    at B = 1), one engine re-recorded per size: loss, heat maps and a spread of gradients against the oracle, and the
+    eval forward of the same engine afterwards."""
+    hc = O.classic_head_cfg(64)
+    bb, hd = O.synth_vit_weights(TOY, seed=1), O.synth_head_weights(hc, seed=2)
+    eng = make_engine(TOY, hc, bb, hd, dev)
+    img, target, tw = O.synth_batch(B, seed=100 + B)
+    loss, heat = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+    torch.cuda.synchronize()
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), hc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert abs(loss.item() - rl.item()) < 3e-2 * rl.item()
+    for n in ('blocks.1.mlp.fc2.weight', 'blocks.0.attn.qkv.weight', 'blocks.0.norm1.weight', 'pos_embed',
+              'patch_embed.proj.weight', 'blocks.1.mlp.fc1.bias'):
+        assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 0.12, n
+    for n in ('final_layer.weight', 'deconv_layers.0.weight', 'deconv_layers.3.weight', 'deconv_layers.4.bias'):
+        assert relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0] < 0.12, n
+    with torch.no_grad():
+        ref_eval = O.head_forward({k: v.detach() for k, v in hdr.items()},
+                                  O.vit_forward({k: v.detach() for k, v in bbr.items()}, img, TOY), hc)
+    # eval after one training pass: the engine's running statistics carry that pass's update, like the oracle's
+    assert relerr(eng.infer(img.to(dev)), ref_eval)[0] < 3e-2
+
+
+def test_empty_batch_is_rejected(dev):
+    hc = O.classic_head_cfg(64)
+    eng = make_engine(TOY, hc, O.synth_vit_weights(TOY, seed=1), O.synth_head_weights(hc, seed=2), dev)
+    with pytest.raises(ValueError):
+        eng.infer(torch.zeros(0, 3, 256, 192, device=dev))
+    with pytest.raises(ValueError):
+        eng.forward_backward(torch.zeros(0, 3, 256, 192, device=dev), torch.zeros(0, 17, 64, 48, device=dev),
+                             torch.zeros(0, 17, 1, device=dev))

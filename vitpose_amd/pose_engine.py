@@ -135,6 +135,8 @@ class PoseEngine:
         exact=True evaluates at fp32 accuracy (see _exact_plan).  dataset_source: per-image dataset indices
         (ViTMoE backbone: selects the FFN expert, vit_moe.py:98-115; None = dataset 0)."""
         B = img.shape[0]
+        if B < 1:
+            raise ValueError('empty batch')
         plan, img_in, heat = self._exact_plan(B) if exact else self._infer_plan(B)
         if self.routed:
             self.vit.set_routing(self.ws_infer, B, dataset_source if dataset_source is not None else [0] * B)
@@ -232,6 +234,8 @@ class PoseEngine:
         returns (loss [1] device tensor, heatmaps [B,K,H,W] device tensor; both are plan-owned) -- with
         associate heads, the lists of both over the heads."""
         B = img.shape[0]
+        if B < 1:
+            raise ValueError('empty batch')
         plan, io = self._train_plan(B)
         self.load_batch(io, img, target, target_weight, dataset_source)
         if dp_scales is not None:
