@@ -1079,7 +1079,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
 
     // 1-D grid over (K slice, tile), slice-major: the contiguous chunk of work ids an XCD receives is a
     // block of neighbouring tiles of ONE K slice, which walk the same operand panels in step (L2 reuse)
-    int work = xcd_remap(blockIdx.x, gridDim.x);
+    // (masked launches mix full-length and short problems: dealing the tile list out to the XCDs round-robin
+    // gives every XCD the same mix, where contiguous eighths would not)
+    int work = KMAP ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     float* rowsum = nullptr;
     int pidx = 0;
     if constexpr (XKMAJ && YKMAJ && EPI == VP_EPI_F32) {

@@ -130,6 +130,15 @@ def _slab_elems(out_elems, K, target_blocks=None):
     return int(4 * tb * 128 * 128 + out_elems)
 
 
+def _long_first(problems):
+    """Order of the problems of one grouped weight-gradient launch that holds expert (image-masked) problems: the
+    full-length ones first, the short ones last.  The masked kernel deals the tile list out to the XCDs round-robin,
+    so every XCD works through the same mix, longest jobs first (994 -> 818 us per launch of 4 ViTPose+-B Blocks)."""
+    full = [p for p in problems if len(p) <= 8 or p[8] is None]
+    short = [p for p in problems if len(p) > 8 and p[8] is not None]
+    return full + short
+
+
 # =====================================================================================
 # ViT backbone
 # =====================================================================================
@@ -461,7 +470,7 @@ class VitRunner:
             if pending:
                 plan.fork()
                 with plan.on_side():
-                    plan.wgrad_group(list(pending), M)
+                    plan.wgrad_group(_long_first(list(pending)), M)
                 pending.clear()
         last = self.depth - 1
         x_last = ws.bufs[f'x_in.{self.depth}']
