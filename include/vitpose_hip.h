@@ -342,6 +342,10 @@ int vp_argmax_rows(const float* x, int rows, int L, int* idx, float* val, vp_str
  * *out += sum x^2.  adamw: grads are multiplied by grad_scale * min(1, max_norm / (sqrt(*gnorm_sq) *
  * grad_scale + 1e-6)) on the fly; p_bf16 (optional) receives the bf16 copy of the new weights. */
 int vp_sumsq_f32(const float* x, size_t n, float* out, vp_stream_t stream);
+/* The same sum with a fixed summation order (per-workgroup partial sums in `partials`, npartials floats of caller-owned
+ * scratch, then one workgroup adds them): bit-identical on every data-parallel replica that holds the same gradients,
+ * which the atomics of vp_sumsq_f32 do not guarantee. */
+int vp_sumsq_f32_det(const float* x, size_t n, float* out, float* partials, int npartials, vp_stream_t stream);
 int vp_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const long* chunk_start,
                   const int* chunk_len, const float* chunk_lr_scale, const float* chunk_wd, int nchunks,
                   float lr, float beta1, float beta2, float eps, int step, const float* gnorm_sq,

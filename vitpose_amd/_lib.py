@@ -95,6 +95,7 @@ SIGNATURES = {
     'vp_mse_loss_nchw': [P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'vp_argmax_rows': [P, c_int, c_int, P, P, P],
     'vp_sumsq_f32': [P, c_size_t, P, P],
+    'vp_sumsq_f32_det': [P, c_size_t, P, P, c_int, P],
     'vp_adamw_step': [P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_float, c_int, P,
                       c_float, c_float, P],
 }

@@ -279,6 +279,37 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 }
 
 // ---------------- gradient norm + AdamW over flat buffers ----------------
+// Deterministic variant: workgroup b writes its partial sum to partial[b]; sumsq_final_kernel adds the partial sums
+// in a fixed order.  Data-parallel replicas compute the clip factor from identical (all-reduced) gradients and must
+// arrive at identical bits, or their weights drift apart step by step (float atomics add in arrival order).
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, size_t n4,
+                                                            float* __restrict__ partial) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int n,
+                                                          float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out += red[0];
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n4, float* __restrict__ out) {
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -397,6 +428,15 @@ extern "C" int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, con
 extern "C" int vp_argmax_rows(const float* x, int rows, int L, int* idx, float* val, hipStream_t stream) {
     VP_CHECK_ARG(x && idx && rows > 0 && L > 0);
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, L, idx, val);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_sumsq_f32_det(const float* x, size_t n, float* out, float* partials, int npartials,
+                                hipStream_t stream) {
+    VP_CHECK_ARG(x && out && partials && n > 0 && n % 4 == 0 && npartials >= 1);
+    const int blocks = npartials < 1024 ? npartials : 1024;      // fixed for a given (n, npartials): same order every call
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, stream, x, n / 4, partials);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, out);
     VP_LAUNCH_RET();
 }
 

@@ -80,6 +80,9 @@ class FlatAdamW:
         self.exp_avg = torch.zeros_like(store.data)
         self.exp_avg_sq = torch.zeros_like(store.data)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # per-workgroup partial sums of the gradient norm: summed in a fixed order, so that every data-parallel
+        # replica derives the same clip factor, bit for bit, from the same all-reduced gradients
+        self.gnorm_partials = torch.zeros(1024, dtype=torch.float32, device=dev)
 
     def step(self, lr: float = None, grad_scale: float = 1.0):
         from . import _lib
@@ -91,9 +94,10 @@ class FlatAdamW:
         gn = None
         if self.max_grad_norm > 0:
             self.gnorm_sq.zero_()
-            rc = L.vp_sumsq_f32(c_void_p(st.grad.data_ptr()), st.numel, c_void_p(self.gnorm_sq.data_ptr()), s)
+            rc = L.vp_sumsq_f32_det(c_void_p(st.grad.data_ptr()), st.numel, c_void_p(self.gnorm_sq.data_ptr()),
+                                    c_void_p(self.gnorm_partials.data_ptr()), self.gnorm_partials.numel(), s)
             if rc:
-                raise RuntimeError(f'vp_sumsq_f32 failed: {rc}')
+                raise RuntimeError(f'vp_sumsq_f32_det failed: {rc}')
             gn = c_void_p(self.gnorm_sq.data_ptr())
         rc = L.vp_adamw_step(
             c_void_p(st.data.data_ptr()), c_void_p(st.grad.data_ptr()), c_void_p(self.exp_avg.data_ptr()),
