@@ -137,17 +137,30 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=8)
     args = ap.parse_args()
 
+    if os.environ.get('VITPOSE_BENCH_WATCHDOG'):        # debugging aid: dump every thread's stack and exit when stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['VITPOSE_BENCH_WATCHDOG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks: VITPOSE_BENCH_SHARE_GPU=1 lets the ranks share
+    # the GPUs that exist and VITPOSE_BENCH_BACKEND=gloo carries the collectives between them (RCCL refuses two ranks
+    # on one device).  The numbers of such a run mean nothing; the driver never sets either variable.
+    dev_index = local_rank
+    if os.environ.get('VITPOSE_BENCH_SHARE_GPU', '0') == '1':
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+    backend = os.environ.get('VITPOSE_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import vitpose_amd.models  # noqa: F401  (registers ViT / TopdownHeatmapSimpleHead / JointsMSELoss / TopDown)
     from vitpose_amd.builder import build_posenet

@@ -24,6 +24,8 @@ class GradBuckets:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.on_gpu = store.device.type == 'cuda'
         self.stream = torch.cuda.Stream(device=store.device) if self.on_gpu else None
+        # asynchronous, stream-ordered collectives (overlapped with the rest of backward) exist with RCCL only
+        self.overlap = self.on_gpu and dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
         self.pending = []
         self.ready_events = []
         # flat layout (forward order): pos/patch, block 0 .. depth-1, last_norm, head
@@ -61,6 +63,13 @@ class GradBuckets:
         if self.world == 1 or hi <= lo:
             return
         g = self.store.grad[lo:hi]
+        if self.on_gpu and not self.overlap:
+            # a backend other than RCCL (gloo, when several ranks rehearse on one GPU): its CUDA collectives block the
+            # host in wait(); issued asynchronously from the autograd thread they were seen to dead-lock after a few
+            # steps, so the bucket is reduced synchronously at its trigger point (no overlap; tests only)
+            torch.cuda.current_stream().synchronize()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            return
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
