@@ -296,3 +296,39 @@ def test_torch_optimizer_and_state_dict_roundtrip(dev):
     with torch.no_grad():
         a, b = model.forward_dummy(img.to(dev)), model2.forward_dummy(img.to(dev))
     assert torch.equal(a, b)
+
+
+def test_topdown_ddp_overlapped_rccl_path_from_the_autograd_thread(dev):
+    """The overlapped RCCL bucket all-reduces when the backward plan runs where it runs in training: inside
+    loss.backward(), on the autograd engine's thread.  One-rank RCCL group with the collectives forced on (sum over one
+    rank = identity); several optimizer steps, the plan replayed each time; the loss of a fixed batch must fall."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        m, bb, hd, ohc = toy_model(dev)
+        m.train()
+        opt = m.build_optimizer(dict(type='AdamW', lr=1e-3, betas=(0.9, 0.999), weight_decay=0.1,
+                                     paramwise_cfg=dict(num_layers=TOY['depth'], layer_decay_rate=0.75)),
+                                grad_clip=dict(max_norm=1., norm_type=2))
+        comm = m.enable_ddp(blocks_per_bucket=1)
+        assert comm.overlap
+        comm.world = 2
+        img, target, tw = O.synth_batch(4, seed=9)
+        img, target, tw = img.to(dev), target.to(dev), tw.to(dev)
+        losses = []
+        for _ in range(6):
+            out = m.forward_train(img, target, tw, None)
+            out['heatmap_loss'].backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(out['heatmap_loss'].item())
+        torch.cuda.synchronize()
+        assert not comm.pending and all(l == l for l in losses)
+        assert losses[-1] < losses[0], losses
+    finally:
+        if created:
+            dist.destroy_process_group()
