@@ -27,8 +27,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bf16=False):
     sys.path.insert(0, ROOT)
+    if bf16:
+        os.environ['VITPOSE_DDP_BF16'] = '1'
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     try:
         dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -58,7 +60,7 @@ def _worker(rank, world, port, q):
         # the bucketed plan
         eng = make()
         comm = eng.enable_ddp(blocks_per_bucket=2)
-        assert comm.world == world and sorted(comm.triggers) == [2, 4]
+        assert comm.world == world and sorted(comm.triggers) == [2, 4] and comm.bf16 == bf16
         eng.setup_optimizer(lr=1e-3, weight_decay=0.1, layer_decay_rate=0.75, max_grad_norm=1.0)
         w0 = eng.store.data.clone()
         eng.forward_backward(x, t, w, drop_path=False)
@@ -108,13 +110,15 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu():
+@pytest.mark.parametrize('bf16', [False, True])
+def test_two_ranks_share_one_gpu(bf16):
+    """bf16 = True: the opt-in VITPOSE_DDP_BF16 exchange (buckets travel as bf16 and are widened back)."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bf16)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

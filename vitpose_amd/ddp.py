@@ -10,6 +10,7 @@ statistics stay per shard).  The per-iteration all-reduce of the logged loss sca
 (mmpose/models/detectors/base.py:66-72) is available as `reduce_scalars`, to be called only on
 logging iterations.
 """
+import os
 from typing import List, Tuple
 
 import torch
@@ -28,6 +29,11 @@ class GradBuckets:
         self.overlap = self.on_gpu and dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
         self.pending = []
         self.ready_events = []
+        # VITPOSE_DDP_BF16=1 (off by default: the reference all-reduces f32): the buckets travel as bf16 -- half the
+        # bytes over xGMI -- and are widened back into the f32 gradient buffer once the collective is done
+        self.bf16 = os.environ.get('VITPOSE_DDP_BF16', '0') == '1' and self.on_gpu
+        self.stage = torch.empty(store.numel, dtype=torch.bfloat16, device=store.device) if self.bf16 else None
+        self.staged = []          # (lo, hi) of buckets that wait to be widened back
         # flat layout (forward order): pos/patch, block 0 .. depth-1, last_norm, head
         off = store.offsets
         end = store.numel
@@ -63,6 +69,10 @@ class GradBuckets:
         if self.world == 1 or hi <= lo:
             return
         g = self.store.grad[lo:hi]
+        if self.bf16:
+            self._cast(self.store.grad, self.stage, lo, hi)      # on the compute stream, before the hand-over event
+            g = self.stage[lo:hi]
+            self.staged.append((lo, hi))
         if self.on_gpu and not self.overlap:
             # a backend other than RCCL (gloo, when several ranks rehearse on one GPU): its CUDA collectives block the
             # host in wait(); issued asynchronously from the autograd thread they were seen to dead-lock after a few
@@ -95,6 +105,26 @@ class GradBuckets:
         for w in self.pending:
             w.wait()
         self.pending.clear()
+        for lo, hi in self.staged:
+            self._cast(self.stage, self.store.grad, lo, hi)
+        self.staged.clear()
+
+    def _cast(self, src, dst, lo, hi):
+        """dst[lo:hi] = (cast) src[lo:hi] on the current stream (f32 <-> bf16; flat buffers)."""
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        n = hi - lo
+        s_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        a = ctypes.c_void_p(src.data_ptr() + lo * src.element_size())
+        b = ctypes.c_void_p(dst.data_ptr() + lo * dst.element_size())
+        if src.dtype == torch.float32:
+            rc = L.vp_cast_f32_bf16(a, b, n, s_)
+        else:
+            dims, strides = (ctypes.c_int * 4)(1, 1, 1, n), (ctypes.c_long * 4)(0, 0, 0, 1)
+            rc = L.vp_strided_cast(a, _lib.VP_BF16, b, _lib.VP_F32, ctypes.byref(dims), ctypes.byref(strides), s_)
+        if rc != 0:
+            raise RuntimeError(f'gradient cast failed with status {rc}')
 
     @property
     def grad_scale(self):
