@@ -89,7 +89,9 @@ typedef struct vp_gemm_args {
      * image b uses expert route_expert[b].  Y rows (y_kmajor = 0: output columns, the forward product;
      * y_kmajor = 1: reduction rows, the data gradient) at or beyond route_split are read route_delta[expert]
      * ELEMENTS further on than the shared matrix would hold them (a multiple of 8), and bias columns >= route_split
-     * route_bias_delta[expert] floats further on.  All three arrays live on the device.  Uses the 192 x 192 tile
+     * route_bias_delta[expert] floats further on.  All three arrays live on the device; the expert indices are read
+     * by the kernel and cannot be validated by the launcher: every route_expert[b] must index route_delta (the Python
+     * host checks them against num_expert before each batch).  Uses the 192 x 192 tile
      * schedule; route_split % 48 == 0, k-contiguous x, no K split. */
     const int* route_expert; const long* route_delta; const long* route_bias_delta; int route_split;
     /* optional (gather16_C > 0): the Y operand is the reduction-major 16-tap gather of `y`, never materialised --
