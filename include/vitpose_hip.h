@@ -30,7 +30,7 @@ typedef void* vp_stream_t;
 typedef hipStream_t vp_stream_t;
 #endif
 
-#define VP_ABI_VERSION 2
+#define VP_ABI_VERSION 3
 int vp_abi_version(void);
 /* gfx target the library was compiled for, e.g. "gfx950". */
 const char* vp_build_arch(void);
@@ -137,6 +137,22 @@ typedef struct vp_ln_partial {
 } vp_ln_partial;   /* 40 bytes */
 int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats);
 int vp_layernorm_bwd_finalize(const vp_ln_partial* table_dev, int count, int E, vp_stream_t stream);
+/* vp_layernorm_bwd without a workspace argument.  No counterpart in the reference: it is for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * The per-workgroup partial column sums go to a file-scope __device__ array of the library
+ * (VP_LN_STATIC_MAX_BLOCKS * 3 * VP_LN_STATIC_MAX_E floats = 7.5 MiB, held by every GPU the library runs on until
+ * the process ends); the call allocates and frees nothing.  Results are bit-identical to vp_layernorm_bwd called
+ * with a workspace of that many floats.  E > VP_LN_STATIC_MAX_E returns VP_ERR_UNSUPPORTED; at least one of
+ * dgamma / dbeta / dcolsum must be given (the sums cannot be deferred: every call on a GPU shares that GPU's
+ * array, so calls that overlap on one GPU -- two streams, two threads -- race; stream-ordered calls are safe).
+ * The first call on each device looks the array's device address up (hipGetSymbolAddress): make it outside
+ * graph capture. */
+#define VP_LN_STATIC_MAX_E 1280
+#define VP_LN_STATIC_MAX_BLOCKS 512
+int vp_layernorm_bwd_static(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, const float* dres, float* dx, void* dxb_bf16,
+                            const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
+                            float* dcolsum, int M, int E, vp_stream_t stream);
 
 /* ------------------------------------------------------------- Attention --------
  * Attention.forward core, vit.py:102-111: softmax(q k^T * scale) v over all `tokens`

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (first: the library must bind to the HIP runtime tor
 from ctypes import POINTER, Structure, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2   # VP_ABI_VERSION of include/vitpose_hip.h this binding was written for
+ABI_VERSION = 3   # VP_ABI_VERSION of include/vitpose_hip.h this binding was written for
 LIB_PATH = os.environ.get('VITPOSE_HIP_LIB') or os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
 
 VP_EPI_BF16, VP_EPI_GELU, VP_EPI_RESID_F32, VP_EPI_DGELU = 0, 1, 2, 3
@@ -64,6 +64,7 @@ SIGNATURES = {
     'vp_layernorm_fwd': [P, P, P, P, P, P, P, c_int, c_int, c_float, P],
     'vp_layernorm_bwd': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P, c_size_t, P],
     'vp_layernorm_bwd_finalize': [P, c_int, c_int, P],
+    'vp_layernorm_bwd_static': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P],
     'vp_layernorm_bwd_blocks': [c_int, c_int, c_size_t],       # host-side helper: no stream argument
     'vp_attention_fwd': [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     'vp_attention_bwd': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],

@@ -2,8 +2,15 @@
 // One wavefront per row: the row lives in registers (float4 chunks strided by 64 lanes),
 // statistics are fp32 wave reductions, every global access is 8 or 16 bytes per lane.
 // HBM-bound: forward moves 4E (x) + 2E (y) bytes per row; backward 4E+2E in, 4E+2E out.
+#include <mutex>
+
 #include "common.h"
 #include "vitpose_hip.h"
+
+// Partial column sums of vp_layernorm_bwd_static: [512 workgroups][3][E <= 1280] floats (7.5 MiB), part of the
+// code object, so every GPU the library runs on holds one copy until the process ends.  Host code never uses
+// this name as an address: static_scratch() asks the runtime for the device address once per device.
+static __device__ __align__(256) float scratch[VP_LN_STATIC_MAX_BLOCKS * 3 * VP_LN_STATIC_MAX_E];
 
 namespace {
 
@@ -264,6 +271,27 @@ inline int ln_bwd_blocks(int M, int E, size_t workspace_floats) {
     return blocks;
 }
 
+// device address of `scratch` on the current device (looked up on the first call per device, then cached)
+int static_scratch(float** out) {
+    constexpr int MAX_DEVICES = 64;
+    static float* ptr[MAX_DEVICES] = {};
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return VP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return VP_ERR_UNSUPPORTED;
+        ptr[dev] = static_cast<float*>(p);
+    }
+    *out = ptr[dev];
+    return VP_OK;
+}
+
 }  // namespace
 
 extern "C" int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats) {
@@ -329,4 +357,20 @@ extern "C" int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float
         hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * E + 15) / 16), dim3(256), 0, stream, workspace, blocks, E,
                            dgamma, dbeta, dcolsum);
     VP_LAUNCH_RET();
+}
+
+extern "C" int vp_layernorm_bwd_static(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                       const float* gamma, const float* dres, float* dx, void* dxb_bf16,
+                                       const float* rowscale, int rows_per_scale, float* dgamma, float* dbeta,
+                                       float* dcolsum, int M, int E, hipStream_t stream) {
+    VP_CHECK_ARG(E > 0 && M > 0);
+    if (E > VP_LN_STATIC_MAX_E) return VP_ERR_UNSUPPORTED;      // the static scratch holds rows of <= 1280 channels
+    VP_CHECK_ARG(dgamma || dbeta || dcolsum);                   // no deferred sums: the scratch is shared by every call
+    float* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != VP_OK) return rc;
+    // every workgroup overwrites its own [3][E] slice and the finalize pass reads the slices of this launch
+    // only, so nothing of an earlier call has to be cleared
+    return vp_layernorm_bwd(dy_bf16, x, mean, rstd, gamma, dres, dx, dxb_bf16, rowscale, rows_per_scale, dgamma, dbeta,
+                            dcolsum, M, E, ws, (size_t)VP_LN_STATIC_MAX_BLOCKS * 3 * VP_LN_STATIC_MAX_E, stream);
 }
