@@ -40,7 +40,10 @@ MODELS = {
               fwd_gflop=251.66),
 }
 EPI_NAMES = {0: 'VP_EPI_BF16', 1: 'VP_EPI_GELU', 2: 'VP_EPI_RESID_F32', 3: 'VP_EPI_DGELU', 4: 'VP_EPI_SPLITK_F32',
-             5: 'VP_EPI_F32', 6: 'VP_EPI_SCALE_RELU', 7: 'VP_EPI_DRELU', 100: 'grouped weight gradients, VP_EPI_F32'}
+             5: 'VP_EPI_F32', 6: 'VP_EPI_SCALE_RELU', 7: 'VP_EPI_DRELU', 100: 'grouped weight gradients, VP_EPI_F32',
+             202: 'split3 (hi/lo pair operands, 3 MFMAs per fragment pair), VP_EPI_RESID_F32',
+             205: 'split3 (hi/lo pair operands, 3 MFMAs per fragment pair), VP_EPI_F32',
+             208: 'split3 (hi/lo pair operands, 3 MFMAs per fragment pair), VP_EPI_PAIR'}
 
 
 def model_cfg(m):
@@ -135,6 +138,9 @@ def main():
     ap.add_argument('--plus', action='store_true',
                     help='ViTPose+ (ViTMoE backbone, TopDownMoE detector with 6 heads) instead of the headline model')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--exact', action='store_true',
+                    help='--mode infer only: the fp32-accurate evaluation path (test_cfg fp32_exact: split3 GEMMs on '
+                         'hi/lo bf16 pairs, everything else f32) instead of the bf16 path')
     args = ap.parse_args()
 
     if os.environ.get('VITPOSE_BENCH_WATCHDOG'):        # debugging aid: dump every thread's stack and exit when stuck
@@ -167,7 +173,12 @@ def main():
     m = MODELS[args.model]
     torch.manual_seed(0)                                    # identical random-init replicas on every rank
     # reference init: trunc_normal .02 / head normal .001
-    model = build_posenet(plus_model_cfg(m) if args.plus else model_cfg(m)).to(dev)
+    cfg = plus_model_cfg(m) if args.plus else model_cfg(m)
+    if args.exact:
+        if args.mode != 'infer':
+            raise SystemExit('--exact is an evaluation path: use it with --mode infer')
+        cfg['test_cfg']['fp32_exact'] = True
+    model = build_posenet(cfg).to(dev)
     metas = [dict(dataset_idx=i % 6) for i in range(args.batch)] if args.plus else None
     loss_keys = ['main_stream_loss'] + [f'{i}_loss' for i in range(1, 6)] if args.plus else ['heatmap_loss']
     eng = model._engine
@@ -212,10 +223,12 @@ def main():
         def step():
             with torch.no_grad():
                 return model.forward_dummy(img)
-        plan_of = lambda: eng.plans[('infer', B)][0]  # noqa: E731
+        plan_of = lambda: eng.plans[('exact' if args.exact else 'infer', B)][0]  # noqa: E731
         gflop = m['fwd_gflop']
         what = (f'ViTPose-{args.model} 256x192 classic-decoder inference (one eval forward, flip_test off as in '
                 f'tools/analysis/speed_test.py) via TopDown.forward_dummy, batch {B}/GPU, random-init weights')
+        if args.exact:
+            what += ', fp32-accurate path (test_cfg fp32_exact)'
 
     def group(timers):
         groups = {}
@@ -267,14 +280,15 @@ def main():
         value = world * B * args.steps / dt
         # one launcher (vp_gemm_bf16) serves three tile schedules (gemm_kernel 128x128, gemm192_kernel,
         # gemm256_kernel), chosen per shape by timing at plan-record time; the instantiation is <x_kmajor, y_kmajor, epilogue>
-        kname = f'vp_gemm_bf16<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi}>'
+        kname = f'vp_gemm_bf16<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi % 100}>'
         if epi == 100:   # the grouped launcher runs gemm192_kernel / gemm256_kernel<true, true, VP_EPI_F32>
             kname = 'vp_wgrad_grouped_bf16'
         out = {
             'metric': 'images/sec (256x192) ViTPose-B fwd+bwd at 1/2/4/8 GPUs; % bf16 MFMA roofline',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x3 (hi/lo bf16 pairs, f32 accumulate)' if args.exact else 'bf16',
+            'data': 'synthetic',
             'config': {'workload': what, 'parallelism': f'dp{world}', 'global_batch': world * B},
             'step_tflops_per_gpu': round(value * gflop / world / 1e3, 2),
             'frac_of_bf16_mfma_peak': round(value * gflop / world / 1e3 / PEAK_BF16_TFLOPS, 4),

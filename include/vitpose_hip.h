@@ -52,7 +52,8 @@ enum {
     VP_EPI_SPLITK_F32 = 4, /* K slice z of split_k writes its partial sums to out + z*split_stride (f32) */
     VP_EPI_F32 = 5,        /* out(f32) = acc + bias                                             */
     VP_EPI_SCALE_RELU = 6, /* out(bf16) = relu(acc*colscale + bias)                             */
-    VP_EPI_DRELU = 7       /* out(bf16) = acc * (aux(bf16) > 0)                                 */
+    VP_EPI_DRELU = 7,      /* out(bf16) = acc * (aux(bf16) > 0)                                 */
+    VP_EPI_PAIR = 8        /* split3 only: out = hi / lo pair array of act(acc*colscale + bias), act = pair_act */
 };
 
 typedef struct vp_gemm_args {
@@ -100,6 +101,15 @@ typedef struct vp_gemm_args {
      * channels), Y[(b,iy,ix)][(ky*4+kx)*C + c] = dout[b][2iy-1+ky][2ix-1+kx][c] (0 outside; gather16_zero: >= 128
      * bytes of zeros on the device), K = B*H*W, N = 16*C, x_kmajor = y_kmajor = 1, VP_EPI_SPLITK_F32, C % 128 == 0. */
     int gather16_H, gather16_W, gather16_C; const void* gather16_zero;
+    /* split3 = 1: fp32-accurate product on the bf16 matrix cores (the reference computes in fp32: nn.Linear /
+     * conv of vit.py and topdown_heatmap_simple_head.py on CPU tensors).  x and y are hi / lo PAIR arrays: a row
+     * of K values is stored as K / 32 groups of 64 bf16, hi(v[32 j .. 32 j + 31]) then lo(the same values), with
+     * hi = bf16(v), lo = bf16(v - hi); ldx / ldy count pair elements (>= 2 K).  Every K step accumulates
+     * hi*hi + hi*lo + lo*hi in ONE accumulator set.  K % 32 == 0, k-contiguous operands, epilogue VP_EPI_F32,
+     * VP_EPI_RESID_F32 or VP_EPI_PAIR (out = pair array [M][ldo >= 2 N], N % 32 == 0, of act(acc*colscale + bias);
+     * pair_act 0 none, 1 exact-erf GELU, 2 ReLU).  route_* are honoured with VP_EPI_RESID_F32 (route_delta in pair
+     * elements). */
+    int split3; int pair_act;
 } vp_gemm_args;
 
 int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);
@@ -319,25 +329,31 @@ int vp_decode_heatmaps(const float* heat, float* preds, float* maxvals, int maps
                        const float* taps_host, int ntaps, vp_stream_t stream);
 
 /* ----------------------------------------------------- fp32-accurate path ----------
- * Evaluation at the reference's fp32 accuracy (the 1e-3 max-abs heat-map tolerance on arbitrary
- * weights): every GEMM operand is a pair of bf16 arrays hi = bf16(x), lo = bf16(x - hi) and a
- * Linear / conv product is three vp_gemm_bf16 launches (hi*hi + hi*lo + lo*hi, chained through
- * VP_EPI_F32 / VP_EPI_RESID_F32); everything else runs in f32:
- *   vp_finish_f32: y = act(x * colscale + colshift) * rowscale[row / rows_per_scale] + resid, act 0 none /
- *     1 exact-erf GELU / 2 ReLU (bias, nn.GELU vit.py:67, BatchNorm + ReLU simple_head.py:333-334, residual
- *     vit.py:138-139); written as f32 `out` and / or the bf16 pair hi / lo (ld = ldo), rows optionally remapped
- *     (row_map = {div, hi, lo, off} as in vp_gemm_args, NULL = identity);
- *   vp_split_f32: hi / lo (and the f32 remainder x - hi) of a flat buffer (weights);
- *   vp_attention_f32: Attention.forward core (vit.py:102-111) on packed f32 qkv, f32 softmax, f32 out;
- *   vp_patch_im2col_split: vp_patch_im2col with the hi / lo split of the pixels. */
-int vp_finish_f32(const float* x, int ldx, const float* colscale, const float* colshift, int act,
-                  const float* resid, int ldr, const float* rowscale, int rows_per_scale, float* out,
-                  void* hi_bf16, void* lo_bf16, int ldo, int M, int N, const int row_map[4], vp_stream_t stream);
-int vp_split_f32(const float* x, void* hi_bf16, void* lo_bf16, float* lo_f32, size_t n, vp_stream_t stream);
-int vp_attention_f32(const float* qkv, float* out, int B, int H, int head_dim, int tokens, float scale,
-                     vp_stream_t stream);
-int vp_patch_im2col_split(const float* img, void* col_hi_bf16, void* col_lo_bf16, int B, int C, int H, int W,
-                          int patch, int stride, int pad, vp_stream_t stream);
+ * Evaluation at the reference's fp32 accuracy (the 1e-3 max-abs heat-map tolerance on arbitrary weights; the
+ * reference computes every op in fp32).  Every GEMM operand is a hi / lo PAIR array (see vp_gemm_args.split3):
+ * rows of K values stored as K / 32 groups of 64 bf16, hi(v[32 j .. 32 j + 31]) then lo(the same values),
+ * hi = bf16(v), lo = bf16(v - hi); a Linear / conv product is ONE vp_gemm_bf16 launch with split3 = 1
+ * (hi*hi + hi*lo + lo*hi per K step into one f32 accumulator) whose epilogue is f32 (bias, exact GELU, BatchNorm
+ * scale/shift + ReLU, DropPath-free residual) and writes either f32 or the next product's pair operand.
+ *   vp_split_pair_f32: pair array (2 n bf16) of a flat f32 buffer of n values, n % 32 == 0 (weights: tensors that
+ *     start on multiples of 32 elements with rows of a multiple of 32 values keep their row structure);
+ *   vp_layernorm_fwd_pair: vp_layernorm_fwd whose output is the pair array [M][2 E] of LN(x) (relu = 1: of
+ *     max(LN(x), 0), the F.relu of the simple decoder, topdown_heatmap_simple_head.py:282), optionally also f32;
+ *   vp_attention_split: Attention.forward core (vit.py:102-111) on packed f32 qkv [B*tokens][3 E]: Q, K, V and the
+ *     softmax probabilities are split the same way, f32 softmax, output = pair array [B*tokens][2 E];
+ *   vp_patch_im2col_pair: vp_patch_im2col with the hi / lo split of the pixels, pair rows of 2 * C*patch*patch;
+ *   vp_deconv_fwd_split: vp_deconv_fwd_bf16 on pair arrays: in [B*H*W][2 C], wph [4][Cout][8 C] (the pair array of
+ *     the f32 phase matrices), out [B*2H*2W][2 Cout] = pair of relu(acc * colscale + shift) (eval-mode BatchNorm
+ *     folded, topdown_heatmap_simple_head.py:323-334).  C % 32 == 0, Cout % 32 == 0. */
+int vp_split_pair_f32(const float* x, void* pair_bf16, size_t n, vp_stream_t stream);
+int vp_layernorm_fwd_pair(const float* x, const float* gamma, const float* beta, void* y_pair, float* y_f32,
+                          int relu, int M, int E, float eps, vp_stream_t stream);
+int vp_attention_split(const float* qkv, void* out_pair, int B, int H, int head_dim, int tokens, float scale,
+                       vp_stream_t stream);
+int vp_patch_im2col_pair(const float* img, void* col_pair, int B, int C, int H, int W, int patch, int stride, int pad,
+                         vp_stream_t stream);
+int vp_deconv_fwd_split(const void* in_pair, const void* wph_pair, void* out_pair, int B, int H, int W, int C, int Cout,
+                        const float* colscale, const float* shift, const void* zero_page, vp_stream_t stream);
 
 /* ------------------------------------------------------------------ Loss --------
  * JointsMSELoss.forward (mmpose/models/losses/mse_loss.py:24-44) fused with its gradient and the

@@ -586,70 +586,129 @@ def test_gemm256_epilogues_and_splitk(dev, mode):
 
 
 # ------------------------------------------------------------------ fp32-accurate path
-def test_split_and_gemm3_reach_fp32_accuracy(dev):
-    """hi / lo split is exact to ~2^-17 and the three-GEMM product is ~1e-5 from an fp64 product
-    (a single bf16 GEMM is ~4e-3)."""
-    M, N, K = 384, 256, 768
-    x, w, bias = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.05), rnd((N,), dev, 3)
-    xh, xl = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
-    wh, wl = torch.empty_like(w, dtype=torch.bfloat16), torch.empty_like(w, dtype=torch.bfloat16)
-    wlf = torch.empty_like(w)
-    acc = torch.full((M, N), float('nan'), device=dev)
+def to_pair(x):
+    """Reference of the hi / lo pair layout: [R][K] f32 -> [R][2K] bf16, groups of 32 hi then their 32 lo."""
+    R, K = x.shape
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    return torch.stack([hi.view(R, K // 32, 32), lo.view(R, K // 32, 32)], 2).reshape(R, 2 * K).contiguous()
 
-    def build(p):
-        p.split_f32(x, xh, xl, None, M * K)
-        p.split_f32(w, wh, wl, wlf, N * K)
-        p.gemm3(xh, xl, wh, wl, acc, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias)
-    run(build)
-    assert torch.equal(xh, x.bfloat16()) and torch.equal(wlf, w - wh.float())
-    assert torch.equal(xl, (x - xh.float()).bfloat16())
-    assert (x - xh.float() - xl.float()).abs().max() <= x.abs().max() * 2 ** -16
+
+def from_pair(p):
+    R, K2 = p.shape
+    v = p.float().view(R, K2 // 64, 2, 32)
+    return (v[:, :, 0] + v[:, :, 1]).reshape(R, K2 // 2)
+
+
+def test_split_pair_layout(dev):
+    x = rnd((96, 160), dev, 1)
+    pair = torch.zeros(96, 320, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.split_pair(x, pair, x.numel()))
+    assert torch.equal(pair, to_pair(x))
+    assert (from_pair(pair) - x).abs().max() <= x.abs().max() * 2 ** -16
+
+
+@pytest.mark.parametrize('mode', [1, 2, 3, 4])
+@pytest.mark.parametrize('M,N,K', [(384, 256, 768), (200, 136, 96), (192, 192, 32), (768, 512, 1024)])
+def test_split3_gemm_reaches_fp32_accuracy(dev, mode, M, N, K):
+    """One split3 launch on pair operands is ~1e-5 from an fp64 product (a single bf16 GEMM is ~4e-3), for every
+    tile schedule; integer operands (lo = 0) come out exactly."""
+    from vitpose_amd import _lib
+    x, w, bias = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.05), rnd((N,), dev, 3)
+    xp, wp = to_pair(x), to_pair(w)
+    acc = torch.full((M, N), float('nan'), device=dev)
+    run(lambda p: p.gemm(xp, wp, acc, M, N, K, ldx=2 * K, ldy=2 * K, ldo=N, epilogue=_lib.VP_EPI_F32, bias=bias,
+                         split3=True, tile_mode=mode))
     ref = (x.double() @ w.double().t() + bias.double()).float()
     err = (acc - ref).abs().max().item()
-    one = (xh.float() @ wh.float().t() + bias - ref).abs().max().item()
-    assert err < 2e-4 * ref.abs().max().item() and err < one / 50, (err, one)
+    one = (x.bfloat16().float() @ w.bfloat16().float().t() + bias - ref).abs().max().item()
+    assert err < 2e-4 * ref.abs().max().item() and err < one / 30, (err, one)
+    xi, wi = ints((M, K), dev, seed=4), ints((N, K), dev, seed=5)
+    run(lambda p: p.gemm(to_pair(xi), to_pair(wi), acc, M, N, K, ldx=2 * K, ldy=2 * K, ldo=N, epilogue=_lib.VP_EPI_F32,
+                         split3=True, tile_mode=mode))
+    assert torch.equal(acc, xi @ wi.t())
 
 
-def test_finish_f32_variants(dev):
-    M, N = 384, 256
-    x, cs, sh, res = rnd((M, N), dev, 1), rnd((N,), dev, 2), rnd((N,), dev, 3), rnd((M, N), dev, 4)
-    rs = torch.rand(2, device=dev) + 0.5
-    out = torch.empty(M, N, device=dev)
-    hi = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    lo = torch.empty_like(hi)
-    run(lambda p: p.finish_f32(x, M, N, ldx=N, ldo=N, out=out, hi=hi, lo=lo, colscale=cs, colshift=sh, act=1,
-                               resid=res, ldr=N, rowscale=rs, rows_per_scale=192))
-    ref = torch.nn.functional.gelu(x * cs + sh) * rs.repeat_interleave(192)[:, None] + res
-    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
-    assert torch.equal(hi, out.bfloat16()) and torch.equal(lo, (out - hi.float()).bfloat16())
-    # ReLU + sub-pixel row remap (phase (1, 0) of a 2x up-sampled 4 x 3 grid, batch 2)
-    B, H, W = 2, 4, 3
-    z = rnd((B * H * W, 64), dev, 5)
-    full = torch.zeros(B * 4 * H * W, 64, device=dev, dtype=torch.bfloat16)
-    run(lambda p: p.finish_f32(z, B * H * W, 64, ldx=64, ldo=64, hi=full, act=2, row_map=(W, 4 * W, 2, 2 * W)))
-    want = torch.zeros(B, 2 * H, 2 * W, 64, device=dev)
-    want[:, 1::2, 0::2] = z.relu().view(B, H, W, 64)
-    assert torch.equal(full.view(B, 2 * H, 2 * W, 64).float(), want.bfloat16().float())
+@pytest.mark.parametrize('mode', [1, 2, 3, 4])
+def test_split3_gemm_epilogues(dev, mode):
+    from vitpose_amd import _lib
+    M, N, K, T = 384, 256, 128, 192
+    x, w = rnd((M, K), dev, 3), rnd((N, K), dev, 4, 0.1)
+    bias, cs = rnd((N,), dev, 5), rnd((N,), dev, 6)
+    xp, wp = to_pair(x), to_pair(w)
+    acc = (x.double() @ w.double().t()).float()
+    # residual + per-sample row scale; position rows
+    resid, pos = rnd((M, N), dev, 7), rnd((T, N), dev, 8)
+    rs = torch.tensor([0.5, 1.0 / 0.7], device=dev)
+    o32 = torch.empty(M, N, device=dev)
+    run(lambda p: p.gemm(xp, wp, o32, M, N, K, ldx=2 * K, ldy=2 * K, ldo=N, bias=bias, resid=resid, rowscale=rs,
+                         rows_per_scale=T, epilogue=_lib.VP_EPI_RESID_F32, split3=True, tile_mode=mode))
+    torch.testing.assert_close(o32, resid + rs.repeat_interleave(T)[:, None] * (acc + bias), rtol=1e-4, atol=1e-4)
+    run(lambda p: p.gemm(xp, wp, o32, M, N, K, ldx=2 * K, ldy=2 * K, ldo=N, bias=bias, pos=pos, pos_rows=T,
+                         epilogue=_lib.VP_EPI_RESID_F32, split3=True, tile_mode=mode))
+    torch.testing.assert_close(o32, acc + bias + pos.repeat(2, 1), rtol=1e-4, atol=1e-4)
+    # pair outputs: none / exact GELU / scale + shift + ReLU
+    out = torch.zeros(M, 2 * N, device=dev, dtype=torch.bfloat16)
+    for act, fn in ((0, lambda v: v), (1, torch.nn.functional.gelu), (2, torch.relu)):
+        run(lambda p: p.gemm(xp, wp, out, M, N, K, ldx=2 * K, ldy=2 * K, ldo=2 * N, bias=bias, colscale=cs,
+                             epilogue=_lib.VP_EPI_PAIR, pair_act=act, split3=True, tile_mode=mode))
+        want = fn(acc * cs + bias)
+        got = from_pair(out)
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+        hi = out.view(M, N // 32, 2, 32)[:, :, 0].reshape(M, N)
+        assert (hi.float() - got).abs().max() <= got.abs().max() * 2 ** -8      # the hi half is bf16(value)
+
+
+def test_layernorm_fwd_pair(dev):
+    M, E = 400, 768
+    x, g, b = rnd((M, E), dev, 1) * 2 + 0.3, rnd((E,), dev, 2) + 1, rnd((E,), dev, 3)
+    ref = torch.nn.functional.layer_norm(x.double(), (E,), g.double(), b.double(), 1e-6).float()
+    for relu in (False, True):
+        y = torch.zeros(M, 2 * E, device=dev, dtype=torch.bfloat16)
+        run(lambda p: p.layernorm_fwd_pair(x, g, b, y, M, E, relu=relu))
+        want = ref.relu() if relu else ref
+        torch.testing.assert_close(from_pair(y), want, rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize('H,d', [(2, 32), (6, 64), (2, 80)])
-def test_attention_f32(dev, H, d):
+def test_attention_split(dev, H, d):
     B, T, E = 2, 192, H * d
     qkv = rnd((B * T, 3 * E), dev, 1) * 1.5
-    out = torch.empty(B * T, E, device=dev)
-    run(lambda p: p.attention_f32(qkv, out, B, H, d, T, d ** -0.5))
+    out = torch.zeros(B * T, 2 * E, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.attention_split(qkv, out, B, H, d, T, d ** -0.5))
     ref, _ = _attn_ref(qkv.double(), B, H, d, d ** -0.5)
-    torch.testing.assert_close(out, ref.float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(from_pair(out), ref.float(), rtol=1e-4, atol=1e-4)   # scores carry ~2^-16 of |q||k|
 
 
-def test_patch_im2col_split(dev):
+def test_patch_im2col_pair(dev):
     B = 2
     img = rnd((B, 3, 256, 192), dev, 1)
-    ch = torch.empty(B * 192, 768, device=dev, dtype=torch.bfloat16)
-    cl = torch.empty_like(ch)
-    run(lambda p: p.patch_im2col_split(img, ch, cl, B, 3, 256, 192, 16, 16, 2))
+    col = torch.zeros(B * 192, 2 * 768, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.patch_im2col_pair(img, col, B, 3, 256, 192, 16, 16, 2))
     ref = torch.nn.functional.unfold(img, 16, padding=2, stride=16).transpose(1, 2).reshape(B * 192, 768)
-    assert torch.equal(ch, ref.bfloat16()) and torch.equal(cl, (ref - ch.float()).bfloat16())
+    assert torch.equal(col, to_pair(ref))
+
+
+def test_deconv_fwd_split(dev):
+    """ConvTranspose2d(k4, s2, p1) + folded BatchNorm + ReLU on pair arrays against torch fp64."""
+    B, H, W, C, Co = 2, 8, 6, 64, 64
+    x = rnd((B, C, H, W), dev, 1)
+    wt = rnd((C, Co, 4, 4), dev, 2, 0.05)
+    cs, sh = rnd((Co,), dev, 3) * 0.2 + 1, rnd((Co,), dev, 4) * 0.1
+    ref = torch.relu(torch.nn.functional.conv_transpose2d(x.double(), wt.double(), stride=2, padding=1)
+                     * cs.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+    xin = to_pair(x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous())
+    # wph[phase][co][(ty, tx, ci)] = W[ci][co][(1 - py) + 2 ty][(1 - px) + 2 tx]
+    wph = torch.empty(4, Co, 4 * C, device=dev)
+    for py in range(2):
+        for px in range(2):
+            sub = wt[:, :, (1 - py)::2, (1 - px)::2]                       # [ci][co][ty][tx]
+            wph[py * 2 + px] = sub.permute(1, 2, 3, 0).reshape(Co, 4 * C)
+    wpp = to_pair(wph.view(4 * Co, 4 * C)).view(4, Co, 8 * C)
+    out = torch.zeros(B * 4 * H * W, 2 * Co, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.deconv_fwd_split(xin, wpp, out, B, H, W, C, Co, cs, sh))
+    got = from_pair(out).view(B, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize('mode', [2, 3])

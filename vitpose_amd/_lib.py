@@ -14,7 +14,7 @@ ABI_VERSION = 3   # VP_ABI_VERSION of include/vitpose_hip.h this binding was wri
 LIB_PATH = os.environ.get('VITPOSE_HIP_LIB') or os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
 
 VP_EPI_BF16, VP_EPI_GELU, VP_EPI_RESID_F32, VP_EPI_DGELU = 0, 1, 2, 3
-VP_EPI_SPLITK_F32, VP_EPI_F32, VP_EPI_SCALE_RELU, VP_EPI_DRELU = 4, 5, 6, 7
+VP_EPI_SPLITK_F32, VP_EPI_F32, VP_EPI_SCALE_RELU, VP_EPI_DRELU, VP_EPI_PAIR = 4, 5, 6, 7, 8
 VP_F32, VP_BF16 = 0, 1
 
 
@@ -35,6 +35,7 @@ class GemmArgs(Structure):
         ('tail_ws', c_void_p), ('tail_ws_bytes', c_size_t), ('tail_force', c_int), ('tile_mode', c_int),
         ('route_expert', c_void_p), ('route_delta', c_void_p), ('route_bias_delta', c_void_p), ('route_split', c_int),
         ('gather16_H', c_int), ('gather16_W', c_int), ('gather16_C', c_int), ('gather16_zero', c_void_p),
+        ('split3', c_int), ('pair_act', c_int),
     ]
 
 
@@ -88,10 +89,11 @@ SIGNATURES = {
     'vp_generate_target': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P],
     'vp_flip_back_avg': [P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
     'vp_decode_heatmaps': [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P],
-    'vp_finish_f32': [P, c_int, P, P, c_int, P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, P, P],
-    'vp_split_f32': [P, P, P, P, c_size_t, P],
-    'vp_attention_f32': [P, P, c_int, c_int, c_int, c_int, c_float, P],
-    'vp_patch_im2col_split': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    'vp_split_pair_f32': [P, P, c_size_t, P],
+    'vp_layernorm_fwd_pair': [P, P, P, P, P, c_int, c_int, c_int, c_float, P],
+    'vp_attention_split': [P, P, c_int, c_int, c_int, c_int, c_float, P],
+    'vp_patch_im2col_pair': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    'vp_deconv_fwd_split': [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     'vp_heatmap_loss': [P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'vp_mse_loss_nchw': [P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'vp_argmax_rows': [P, c_int, c_int, P, P, P],

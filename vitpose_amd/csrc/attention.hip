@@ -307,7 +307,160 @@ __global__ __launch_bounds__(256, (D & (D - 1)) == 0 ? 3 : 2) void attn_bwd_kern
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp32-accurate forward (evaluation): f32 packed qkv in, hi / lo pair array out.  Q, K, V and the
+// probabilities are split into hi = bf16(x), lo = bf16(x - hi) and every product runs as
+// hi*hi + hi*lo + lo*hi on the bf16 matrix cores (f32 accumulation, f32 softmax).  K and V hi / lo images
+// sit in LDS (four images: one workgroup per CU).
+template <int D>
+__device__ __forceinline__ void frag_global_split(const float* row_li, int g, Frag<D>& hi, Frag<D>& lo) {
+    auto cvt = [](const float* p, bf16x8& h, bf16x8& l) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = (bf16)a[j];
+            h[4 + j] = (bf16)b[j];
+            l[j] = (bf16)(a[j] - (float)h[j]);
+            l[4 + j] = (bf16)(b[j] - (float)h[4 + j]);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) cvt(row_li + 32 * s + 8 * g, hi.f[s], lo.f[s]);
+    if constexpr (D % 32 == 16) {
+        bf16x8 h, l;
+        cvt(row_li + (D - 16) + 8 * (g & 1), h, l);
+        hi.f[D / 32] = g < 2 ? h : zero8();
+        lo.f[D / 32] = g < 2 ? l : zero8();
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_split_kernel(const float* __restrict__ qkv, bf16* __restrict__ out_pair,
+                                                            int H, int E, float scale) {
+    using I = Img<D>;
+    __shared__ __attribute__((aligned(16))) char lds[4 * I::BYTES];
+    char* kh = lds;
+    char* kl = lds + I::BYTES;
+    char* vh = lds + 2 * I::BYTES;
+    char* vl = lds + 3 * I::BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const size_t ld = 3 * (size_t)E;
+    const float* base = qkv + (size_t)b * NTOK * ld + h * D;
+    constexpr int CH = D / 8;
+    for (int idx = tid; idx < NTOK * CH; idx += 256) {
+        const int row = idx / CH, c8 = idx % CH;
+        const float* pk = base + E + (size_t)row * ld + c8 * 8;
+        const float* pv = base + 2 * E + (size_t)row * ld + c8 * 8;
+        bf16x8 hi, lo;
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(pk), k1 = *reinterpret_cast<const f32x4*>(pk + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(pv), v1 = *reinterpret_cast<const f32x4*>(pv + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = (bf16)k0[j];
+            hi[4 + j] = (bf16)k1[j];
+            lo[j] = (bf16)(k0[j] - (float)hi[j]);
+            lo[4 + j] = (bf16)(k1[j] - (float)hi[4 + j]);
+        }
+        *reinterpret_cast<bf16x8*>(kh + I::off16(row, c8)) = hi;
+        *reinterpret_cast<bf16x8*>(kl + I::off16(row, c8)) = lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = (bf16)v0[j];
+            hi[4 + j] = (bf16)v1[j];
+            lo[j] = (bf16)(v0[j] - (float)hi[j]);
+            lo[4 + j] = (bf16)(v1[j] - (float)hi[4 + j]);
+        }
+        *reinterpret_cast<bf16x8*>(vh + I::off16(row, c8)) = hi;
+        *reinterpret_cast<bf16x8*>(vl + I::off16(row, c8)) = lo;
+    }
+    __syncthreads();
+    const float c = scale * 1.44269504088896340736f;
+#pragma unroll 1
+    for (int qt = 0; qt < 3; ++qt) {
+        const int q0 = wave * 48 + qt * 16;
+        Frag<D> qh, ql;
+        frag_global_split<D>(base + (size_t)(q0 + li) * ld, g, qh, ql);
+        f32x4 sc[12];
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt) {
+            const Frag<D> fh = I::frag(kh, 16 * kt, lane);
+            f32x4 a = mfma_d<D>(fh, qh, f32x4{0.f, 0.f, 0.f, 0.f});
+            a = mfma_d<D>(fh, ql, a);
+            sc[kt] = mfma_d<D>(I::frag(kl, 16 * kt, lane), qh, a);
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[kt][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        const float mc = m * c;
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[kt][r] = exp2f(sc[kt][r] * c - mc);
+                l += sc[kt][r];
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        f32x4 o[D / 16];
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const bf16x8 ph = pack8(sc[2 * ks], sc[2 * ks + 1]);
+            f32x4 r0, r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r0[j] = sc[2 * ks][j] - (float)ph[j];
+                r1[j] = sc[2 * ks + 1][j] - (float)ph[4 + j];
+            }
+            const bf16x8 pl = pack8(r0, r1);
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const bf16x8 fvh = I::cols(vh, ks, dt, lane);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fvh, ph, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fvh, pl, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(vl, ks, dt, lane), ph, o[dt], 0, 0, 0);
+            }
+        }
+        bf16* orow = out_pair + ((size_t)b * NTOK + q0 + li) * 2 * E;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) {
+            const int n = h * D + 16 * dt + 4 * g;
+            const f32x4 v = o[dt] * inv;
+            const bf16x4 hi = pack4(v[0], v[1], v[2], v[3]);
+            bf16* p = orow + ((n >> 5) << 6) + (n & 31);
+            *reinterpret_cast<bf16x4*>(p) = hi;
+            *reinterpret_cast<bf16x4*>(p + 32) =
+                pack4(v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int vp_attention_split(const float* qkv, void* out_pair, int B, int H, int head_dim, int tokens, float scale,
+                                  hipStream_t stream) {
+    VP_CHECK_ARG(qkv && out_pair && B > 0 && H > 0);
+    if (tokens != NTOK) return VP_ERR_UNSUPPORTED;
+    const int E = H * head_dim;
+    VP_CHECK_ARG(E % 32 == 0);
+    dim3 grid(B * H), block(256);
+    switch (head_dim) {
+        case 32: hipLaunchKernelGGL(attn_split_kernel<32>, grid, block, 0, stream, qkv, (bf16*)out_pair, H, E, scale); break;
+        case 64: hipLaunchKernelGGL(attn_split_kernel<64>, grid, block, 0, stream, qkv, (bf16*)out_pair, H, E, scale); break;
+        case 80: hipLaunchKernelGGL(attn_split_kernel<80>, grid, block, 0, stream, qkv, (bf16*)out_pair, H, E, scale); break;
+        default: return VP_ERR_UNSUPPORTED;
+    }
+    VP_LAUNCH_RET();
+}
 
 extern "C" int vp_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int head_dim, int tokens,
                                 float scale, hipStream_t stream) {

@@ -104,6 +104,7 @@ struct Epi {
     const float* colscale;
     int row_div, row_hi, row_lo, row_off;  // out row = (i / div) * hi + (i % div) * lo + off when div > 0
     long split_stride;                     // elements between the K-slice slabs of VP_EPI_SPLITK_F32
+    int pair_act;                          // VP_EPI_PAIR: 0 none, 1 exact GELU, 2 ReLU
 };
 
 // Epilogue of one wave's 64x64 sub-tile.  All per-column (bias / colscale) and per-row
@@ -159,7 +160,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
             for (int b = 0; b < FN; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
         }
     }
-    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU) {
+    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU || EPI == VP_EPI_PAIR) {
         if (e.colscale) {
 #pragma unroll
             for (int b = 0; b < FN; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
@@ -190,6 +191,27 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
                 if (VP_ST_OK(ok)) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        } else if constexpr (EPI == VP_EPI_PAIR) {
+            // hi / lo pair layout: column n of the row lives at (n / 32) * 64 + n % 32 (hi) and 32 further on (lo)
+            bf16* o = (bf16*)e.out + orow * e.ldo;
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                f32x4 v = acc[a][b] * cs[b] + bias[b];
+                if (e.pair_act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752440f));
+                } else if (e.pair_act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                const bf16x4 h = pack4(v[0], v[1], v[2], v[3]);
+                const bf16x4 l = pack4(v[0] - (float)h[0], v[1] - (float)h[1], v[2] - (float)h[2], v[3] - (float)h[3]);
+                const int pc = ((col[b] >> 5) << 6) | (col[b] & 31);
+                if (VP_ST_OK(rok && cok[b])) {
+                    *reinterpret_cast<bf16x4*>(o + pc) = h;
+                    *reinterpret_cast<bf16x4*>(o + pc + 32) = l;
+                }
             }
         } else if constexpr (EPI == VP_EPI_RESID_F32) {
             // out = addend + rowscale[row / rows_per_scale] * (acc + bias), addend = resid row or pos row
@@ -339,7 +361,12 @@ constexpr bool epi_is_bf16() {
            EPI == VP_EPI_DRELU;
 }
 
-template <bool XKMAJ, bool YKMAJ, int EPI>
+// SPLIT3 (every tile schedule below): both operands are hi / lo PAIR arrays -- each 64-element K step of a row holds
+// hi(x[32 j .. 32 j + 31]) then lo(the same 32 values), hi = bf16(x), lo = bf16(x - hi) -- and a K step
+// accumulates hi*hi + hi*lo + lo*hi (three MFMAs per fragment pair, one accumulator set, one epilogue): an
+// fp32-accurate product (the dropped lo*lo term is ~2^-16 relative) on the bf16 matrix cores.  The LDS images and
+// loaders are those of the plain kernels: sub-step 0 of a staged tile is the hi half, sub-step 1 the lo half.
+template <bool XKMAJ, bool YKMAJ, int EPI, bool SPLIT3 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y, int M, int N, int K,
                                                            int tiles_n, int ntiles, int ksplit_tiles, Epi e,
                                                            Tail tl) {
@@ -396,6 +423,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
 #endif
             const char* lx = lds[cur][0];
             const char* ly = lds[cur][1];
+            if constexpr (SPLIT3) {
+                bf16x8 xf[4][2], yf[4][2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) xf[a][s] = read_frag<XKMAJ>(lx, wm * 64 + a * 16, s, lane);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) yf[b][s] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][t == 2], xf[a][t == 1], acc[a][b], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 xf[4], yf[4];
@@ -413,6 +457,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
                         asm volatile("" ::"v"(yf[b]), "v"(xf[a]));
 #endif
                     }
+            }
             }
             __syncthreads();
         }
@@ -556,7 +601,7 @@ __device__ __forceinline__ void stage_tile_gather(const bf16* in, const Gather& 
     }
 }
 
-template <bool YKMAJ, int EPI, bool GATHER = false>
+template <bool YKMAJ, int EPI, bool GATHER = false, bool SPLIT3 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand Y, int M, int N, int K, int tiles_n,
                                                               int ntiles, Epi e, Gather gth = Gather{}) {
     __shared__ __attribute__((aligned(16))) char lds[2][W_XBYTES + W_YBYTES];
@@ -607,6 +652,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand
         }
         const char* lx = lds[cur];
         const char* ly = lds[cur] + W_XBYTES;
+        if constexpr (SPLIT3) {
+            bf16x8 xf[6][2], yf[4][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) yf[b][s] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) xf[a][s] = read_frag<false>(lx, wm * 96 + a * 16, s, lane);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][t == 2], xf[a][t == 1], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        } else
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 xf[6], yf[4];
@@ -782,7 +846,7 @@ __device__ __forceinline__ void stage_half_gather_y(const bf16* dout, const Gath
     }
 }
 
-template <bool XKMAJ, bool YKMAJ, int EPI, bool GY = false>
+template <bool XKMAJ, bool YKMAJ, int EPI, bool GY = false, bool SPLIT3 = false>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Operand Y, int M, int N, int K,
                                                                 int tiles_n, int ntiles, int ksplit_tiles, Epi e,
                                                                 const vp_group_entry* gtab, int ngtab,
@@ -873,12 +937,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
+                                                                          acc[a][b], 0, 0, 0);
             if constexpr (RS) {
                 {
 #pragma unroll
@@ -900,12 +965,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][s], xf[a][s], acc[a][2 + b], 0, 0, 0);
+                        acc[a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
+                                                                          acc[a][2 + b], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---- phase 2
@@ -917,13 +983,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[4 + a][2 + b] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][s], xf[a][s], acc[4 + a][2 + b], 0, 0, 0);
+                        acc[4 + a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
+                                                                          acc[4 + a][2 + b], 0, 0, 0);
             if constexpr (RS) {
                 {
 #pragma unroll
@@ -943,12 +1009,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][s], xf[a][s], acc[4 + a][b], 0, 0, 0);
+                        acc[4 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
+                                                                          acc[4 + a][b], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             VP_WAIT_VM(2);
             __builtin_amdgcn_s_barrier();
@@ -1067,7 +1134,7 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s,
 // KMAP (grouped weight gradients only): a problem may reduce over a SUBSET of the images whose rows make up the
 // K extent: bit b of its image_mask words selects image b (tiles_per_image K tiles each; no bit set = the output
 // is written as zeros).  The K loop walks the set bits with scalar ALU work only (no memory access in the loop).
-template <bool XKMAJ, bool YKMAJ, int EPI, bool ROUTE = false, bool KMAP = false>
+template <bool XKMAJ, bool YKMAJ, int EPI, bool ROUTE = false, bool KMAP = false, bool SPLIT3 = false>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Operand Y, int M, int N, int K,
                                                                 int tiles_n, int ntiles, int ksplit_tiles, Epi e,
                                                                 const vp_group_entry* gtab, int ngtab,
@@ -1202,12 +1269,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
                     for (int b = 0; b < 3; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
+                                                                          acc[a][b], 0, 0, 0);
             if constexpr (RS) {
                 {
 #pragma unroll
@@ -1232,13 +1300,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
                     for (int b = 0; b < 3; ++b)
-                        acc[3 + a][b] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[3 + a][b], 0, 0, 0);
+                        acc[3 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
+                                                                          acc[3 + a][b], 0, 0, 0);
             if constexpr (RS) {
                 {
 #pragma unroll
@@ -1469,11 +1537,87 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
     VP_LAUNCH_RET();
 }
 
+// hi / lo pair operands (vp_gemm_args.split3): k-contiguous X and Y only, epilogues F32 / RESID_F32 / PAIR; the
+// kernels see a reduction extent of 2 K pair elements.
+int launch_split3(const vp_gemm_args* a, hipStream_t st) {
+    const int K2 = 2 * a->K;
+    Operand X{(const bf16*)a->x, a->ldx, a->M}, Y{(const bf16*)a->y, a->ldy, a->N};
+    Epi e{a->epilogue, a->out, a->ldo, a->out2, a->bias, a->resid, a->rowscale, a->rows_per_scale,
+          a->aux, a->ldaux, a->pos, a->pos_rows, a->colscale,
+          a->out_row_div, a->out_row_hi, a->out_row_lo, a->out_row_off, a->split_stride, a->pair_act};
+#define VP_S3_SWITCH(LAUNCH)                                  \
+    switch (a->epilogue) {                                    \
+        case VP_EPI_F32: LAUNCH(VP_EPI_F32); break;           \
+        case VP_EPI_RESID_F32: LAUNCH(VP_EPI_RESID_F32); break; \
+        case VP_EPI_PAIR: LAUNCH(VP_EPI_PAIR); break;         \
+        default: return VP_ERR_UNSUPPORTED;                   \
+    }
+    if (a->route_expert) {
+        if (a->M % T3 != 0 || a->route_split % 48 != 0 || !a->route_delta) return VP_ERR_UNSUPPORTED;
+        if (a->epilogue != VP_EPI_RESID_F32) return VP_ERR_UNSUPPORTED;
+        const int tn3 = (a->N + T3 - 1) / T3, nt3 = (a->M / T3) * tn3;
+        const Route rt{a->route_expert, a->route_delta, a->route_bias_delta, a->route_split};
+        hipLaunchKernelGGL((gemm192_kernel<false, false, VP_EPI_RESID_F32, true, false, true>), dim3(nt3), dim3(T2_THREADS),
+                           0, st, X, Y, a->M, a->N, K2, tn3, nt3, K2 / BK, e, nullptr, 0, rt);
+        VP_LAUNCH_RET();
+    }
+    int mode = a->tile_mode;
+    if (mode == 0) {
+        const int tm2 = (a->M + T2 - 1) / T2, tn2 = (a->N + T2 - 1) / T2;
+        mode = use_big_tiles(a->M, a->N, K2, tm2 * tn2, num_cus()) ? 2 : 1;
+        if (mode == 1 && a->M % T3 == 0 && a->N % T3 == 0 && a->M >= 2 * T3) mode = 3;
+    }
+    if (mode == 4) {
+        const int tm = (a->M + W_BM - 1) / W_BM, tn = (a->N + W_BN - 1) / W_BN, nt = tm * tn;
+#define VP_S3_W2(EPI)                                                                                          \
+    hipLaunchKernelGGL((gemm_w2_kernel<false, EPI, false, true>), dim3(nt), dim3(NTHREADS), 0, st, X, Y, a->M, \
+                       a->N, K2, tn, nt, e)
+        VP_S3_SWITCH(VP_S3_W2)
+#undef VP_S3_W2
+    } else if (mode == 3) {
+        const int tm = (a->M + T3 - 1) / T3, tn = (a->N + T3 - 1) / T3, nt = tm * tn;
+#define VP_S3_192(EPI)                                                                                              \
+    hipLaunchKernelGGL((gemm192_kernel<false, false, EPI, false, false, true>), dim3(nt), dim3(T2_THREADS), 0, st, \
+                       X, Y, a->M, a->N, K2, tn, nt, K2 / BK, e, nullptr, 0)
+        VP_S3_SWITCH(VP_S3_192)
+#undef VP_S3_192
+    } else if (mode == 2) {
+        const int tm = (a->M + T2 - 1) / T2, tn = (a->N + T2 - 1) / T2, nt = tm * tn;
+#define VP_S3_256(EPI)                                                                                          \
+    hipLaunchKernelGGL((gemm256_kernel<false, false, EPI, false, true>), dim3(nt), dim3(T2_THREADS), 0, st, X, \
+                       Y, a->M, a->N, K2, tn, nt, K2 / BK, e, nullptr, 0)
+        VP_S3_SWITCH(VP_S3_256)
+#undef VP_S3_256
+    } else {
+        const int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN, nt = tm * tn;
+        const Tail tl{nt, 1, nullptr};
+#define VP_S3_128(EPI)                                                                                         \
+    hipLaunchKernelGGL((gemm_kernel<false, false, EPI, true>), dim3(nt, 1), dim3(NTHREADS), 0, st, X, Y, a->M, \
+                       a->N, K2, tn, nt, K2 / BK, e, tl)
+        VP_S3_SWITCH(VP_S3_128)
+#undef VP_S3_128
+    }
+#undef VP_S3_SWITCH
+    VP_LAUNCH_RET();
+}
+
 }  // namespace
 
 extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
     VP_CHECK_ARG(a && a->x && a->y && a->out);
     VP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
+    if (a->split3) {
+        // hi / lo pair operands: 32 values per 64-element K step; rows of 2 K pair elements
+        VP_CHECK_ARG(a->K % 32 == 0 && a->N % 4 == 0 && !a->x_kmajor && !a->y_kmajor && a->gather16_C == 0);
+        VP_CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && a->ldo % 4 == 0 && a->ldx >= 2 * a->K && a->ldy >= 2 * a->K);
+        VP_CHECK_ARG(((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->y & 15) == 0 && ((uintptr_t)a->out & 15) == 0);
+        if (a->epilogue == VP_EPI_PAIR)
+            VP_CHECK_ARG(a->N % 32 == 0 && a->ldo >= 2 * a->N && a->pair_act >= 0 && a->pair_act <= 2);
+        if (a->rowscale) VP_CHECK_ARG(a->rows_per_scale > 0);
+        if (a->pos) VP_CHECK_ARG(a->pos_rows > 0);
+        return launch_split3(a, stream);
+    }
+    if (a->epilogue == VP_EPI_PAIR) return VP_ERR_UNSUPPORTED;   // pair outputs come from pair operands
     VP_CHECK_ARG(a->K % BK == 0);          // reduction extent: whole 64-wide steps
     VP_CHECK_ARG(a->N % 4 == 0);           // epilogue handles 4 columns per lane
     VP_CHECK_ARG(a->ldx % 8 == 0 && a->ldy % 8 == 0 && a->ldo % 4 == 0);
@@ -1592,5 +1736,28 @@ extern "C" int vp_deconv_fwd_bf16(const void* in, const void* wph, void* out, in
     else
         hipLaunchKernelGGL((gemm_w2_kernel<false, VP_EPI_SCALE_RELU, true>), grid, dim3(NTHREADS), 0, stream, X, Y, M,
                            Cout, K, tn, tm * tn, e, g);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_deconv_fwd_split(const void* in_pair, const void* wph_pair, void* out_pair, int B, int H, int W, int C,
+                                   int Cout, const float* colscale, const float* shift, const void* zero_page,
+                                   hipStream_t stream) {
+    VP_CHECK_ARG(in_pair && wph_pair && out_pair && zero_page && B > 0 && H > 0 && W > 0);
+    VP_CHECK_ARG(C % 32 == 0 && Cout % 32 == 0);
+    VP_CHECK_ARG(((uintptr_t)in_pair & 15) == 0 && ((uintptr_t)wph_pair & 15) == 0 && ((uintptr_t)out_pair & 15) == 0);
+    // the plain implicit-GEMM loader on pair rows: a pixel has 2 C pair elements, a tap 2 C reduction steps
+    const int M = B * H * W, C2 = 2 * C, K2 = 4 * C2;
+    Operand X{(const bf16*)in_pair, C2, M}, Y{(const bf16*)wph_pair, K2, Cout};
+    Epi e{};
+    e.kind = VP_EPI_PAIR;
+    e.out = out_pair;
+    e.ldo = 2 * Cout;
+    e.bias = shift;
+    e.colscale = colscale;
+    e.pair_act = 2;
+    Gather g{H, W, C2, (const bf16*)zero_page, 0};
+    const int tm = (M + W_BM - 1) / W_BM, tn = (Cout + W_BN - 1) / W_BN;
+    hipLaunchKernelGGL((gemm_w2_kernel<false, VP_EPI_PAIR, true, true>), dim3(tm * tn, 4), dim3(NTHREADS), 0, stream, X, Y,
+                       M, Cout, K2, tn, tm * tn, e, g);
     VP_LAUNCH_RET();
 }

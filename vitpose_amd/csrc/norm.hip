@@ -16,11 +16,14 @@ namespace {
 
 // CH = float4 chunks per lane (row length E <= 256 * CH); the row loops are fully unrolled so the
 // register footprint follows the actual row length (E = 768 -> 3 chunks) and occupancy stays high.
-template <int CH>
+// PAIR: y is a hi / lo pair array (rows of 2 E bf16: groups of 32 hi values followed by their 32 lo values,
+// hi = bf16(v), lo = bf16(v - hi)) of max(v, 0) when `relu` is set, else of v: the operand of an fp32-accurate GEMM.
+template <int CH, bool PAIR = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean_out,
-                                                     float* __restrict__ rstd_out, int M, int E, float eps) {
+                                                     float* __restrict__ rstd_out, int M, int E, float eps,
+                                                     int relu = 0) {
     const int lane = threadIdx.x & 63;
     const int nch = E >> 2;
     const int nwaves = gridDim.x * 4;
@@ -88,7 +91,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                     o0[r] = (v0[i][r] - m0) * r0 * g[i][r] + b[i][r];
                     o1[r] = (v1[i][r] - m1) * r1 * g[i][r] + b[i][r];
                 }
-                if (y) {
+                if constexpr (PAIR) {
+                    if (relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o0[r] = fmaxf(o0[r], 0.f);
+                            o1[r] = fmaxf(o1[r], 0.f);
+                        }
+                    }
+                    const int pc = ((c >> 3) << 6) | ((c & 7) << 2);     // column 4c of the row in the pair layout
+                    const bf16x4 h0 = pack4(o0[0], o0[1], o0[2], o0[3]), h1 = pack4(o1[0], o1[1], o1[2], o1[3]);
+                    bf16* p0 = y + (size_t)row0 * 2 * E + pc;
+                    *reinterpret_cast<bf16x4*>(p0) = h0;
+                    *reinterpret_cast<bf16x4*>(p0 + 32) = pack4(o0[0] - (float)h0[0], o0[1] - (float)h0[1],
+                                                               o0[2] - (float)h0[2], o0[3] - (float)h0[3]);
+                    if (has1) {
+                        bf16* p1 = y + (size_t)row1 * 2 * E + pc;
+                        *reinterpret_cast<bf16x4*>(p1) = h1;
+                        *reinterpret_cast<bf16x4*>(p1 + 32) = pack4(o1[0] - (float)h1[0], o1[1] - (float)h1[1],
+                                                                   o1[2] - (float)h1[2], o1[3] - (float)h1[3]);
+                    }
+                } else if (y) {
                     *reinterpret_cast<bf16x4*>(y + (size_t)row0 * E + 4 * c) = pack4(o0[0], o0[1], o0[2], o0[3]);
                     if (has1) *reinterpret_cast<bf16x4*>(y + (size_t)row1 * E + 4 * c) = pack4(o1[0], o1[1], o1[2], o1[3]);
                 }
@@ -312,8 +335,8 @@ extern "C" int vp_layernorm_fwd(const float* x, const float* gamma, const float*
     int blocks = (M + 7) / 8;              // 4 waves x 2 rows per pass
     if (blocks > 1536) blocks = 1536;      // persistent: ~24 waves per CU, each walking a few rows
 #define VP_LNF(CH)                                                                                                  \
-    hipLaunchKernelGGL(ln_fwd_kernel<CH>, dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, y_f32, \
-                       mean, rstd, M, E, eps)
+    hipLaunchKernelGGL((ln_fwd_kernel<CH, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, \
+                       y_f32, mean, rstd, M, E, eps, 0)
     switch ((E + 255) / 256) {
         case 1: VP_LNF(1); break;
         case 2: VP_LNF(2); break;
@@ -325,6 +348,29 @@ extern "C" int vp_layernorm_fwd(const float* x, const float* gamma, const float*
         default: VP_LNF(8); break;
     }
 #undef VP_LNF
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_layernorm_fwd_pair(const float* x, const float* gamma, const float* beta, void* y_pair, float* y_f32,
+                                     int relu, int M, int E, float eps, hipStream_t stream) {
+    VP_CHECK_ARG(x && gamma && beta && y_pair);
+    VP_CHECK_ARG(M > 0 && E > 0 && E % 32 == 0 && E <= 256 * 8);
+    int blocks = (M + 7) / 8;
+    if (blocks > 1536) blocks = 1536;
+#define VP_LNP(CH)                                                                                                   \
+    hipLaunchKernelGGL((ln_fwd_kernel<CH, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_pair, \
+                       y_f32, (float*)nullptr, (float*)nullptr, M, E, eps, relu)
+    switch ((E + 255) / 256) {
+        case 1: VP_LNP(1); break;
+        case 2: VP_LNP(2); break;
+        case 3: VP_LNP(3); break;
+        case 4: VP_LNP(4); break;
+        case 5: VP_LNP(5); break;
+        case 6: VP_LNP(6); break;
+        case 7: VP_LNP(7); break;
+        default: VP_LNP(8); break;
+    }
+#undef VP_LNP
     VP_LAUNCH_RET();
 }
 

@@ -44,14 +44,12 @@ class ParamStore:
         self.half = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
         self.exp_avg = None
         self.exp_avg_sq = None
-        # fp32-accurate evaluation: remainder data - float(half), as f32 and rounded to bf16 (on demand)
-        self.data_lo = None
-        self.half_lo = None
+        # fp32-accurate evaluation: the hi / lo pair array of `data` (2 bf16 per value, groups of 32; on demand)
+        self.pair = None
 
-    def ensure_lo(self):
-        if self.half_lo is None:
-            self.data_lo = torch.zeros_like(self.data)
-            self.half_lo = torch.zeros_like(self.half)
+    def ensure_pair(self):
+        if self.pair is None:
+            self.pair = torch.zeros(2 * self.numel, dtype=torch.bfloat16, device=self.device)
 
     def _v(self, buf, name):
         o = self.offsets[name]
@@ -67,11 +65,14 @@ class ParamStore:
     def hview(self, name):
         return self._v(self.half, name)
 
-    def lview(self, name):
-        return self._v(self.half_lo, name)
-
-    def lfview(self, name):
-        return self._v(self.data_lo, name)
+    def pview(self, name):
+        """[rows][2 * K] pair array of a weight [rows][K...] (K = product of the trailing extents, % 32 == 0)."""
+        o = self.offsets[name]
+        s = self.shapes[name]
+        n = int(math.prod(s))
+        if (n // s[0]) % 32:
+            raise ValueError(f'{name}: rows of {n // s[0]} values have no pair layout (multiple of 32 needed)')
+        return self.pair[2 * o:2 * (o + n)].view(s[0], 2 * (n // s[0]))
 
     def load(self, sd: Dict[str, torch.Tensor], strict=True):
         for n in self.names:
@@ -340,55 +341,50 @@ class VitRunner:
         return feat
 
     # -- fp32-accurate forward (evaluation only) --
-    def record_forward_exact(self, plan: Plan, ws: Workspace, img: torch.Tensor, B: int):
-        """Same network with every Linear evaluated as three bf16 GEMMs on hi / lo operand pairs
-        and everything else in f32.  Returns the f32 token-major output of the last LayerNorm."""
+    def record_forward_exact(self, plan: Plan, ws: Workspace, img: torch.Tensor, B: int, relu_out: bool = False):
+        """Same network at the reference's fp32 accuracy: every Linear is one split3 GEMM on hi / lo pair operands
+        (three MFMAs per fragment pair), everything else f32, fused into the producing kernel.  Returns the
+        pair array [B*T][2E] of the last LayerNorm's output (of its ReLU with `relu_out`: the simple decoder's
+        input transform) -- the operand of the head's first product."""
         E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
         H, W = self.img_hw
         st = self.store
+        F32, RES, PAIR = _lib.VP_EPI_F32, _lib.VP_EPI_RESID_F32, _lib.VP_EPI_PAIR
 
-        def wl(n):
-            return st.lview(self.pre + n)
-        ch, cl = ws.bf16('x_pe_hi', M, self.Kpe), ws.bf16('x_pe_lo', M, self.Kpe)
-        plan.patch_im2col_split(img, ch, cl, B, self.C, H, W, self.patch, self.stride, self.pad)
-        acc = ws.f32('x_acc', M, max(3 * E, Hd))
+        def wp(n):
+            return st.pview(self.pre + n)
+        col = ws.bf16('x_pe_pair', M, 2 * self.Kpe)
+        plan.patch_im2col_pair(img, col, B, self.C, H, W, self.patch, self.stride, self.pad)
         x, xm = ws.f32('x_xa', M, E), ws.f32('x_xb', M, E)
-        plan.gemm3(ch, cl, self.h('patch_embed.proj.weight'), wl('patch_embed.proj.weight'), acc, M, E, self.Kpe,
-                   ldx=self.Kpe, ldy=self.Kpe, ldo=E, bias=self.w('patch_embed.proj.bias'))
-        # + pos_embed[:, 1:] + pos_embed[:, :1] (one [T][E] table, broadcast over images)
-        pos_full = ws.f32('x_pos', M, E)
-        pc = self.pos_comb
-        plan.host(lambda: pos_full.view(B, T, E).copy_(pc.unsqueeze(0).expand(B, T, E)))
-        plan.finish_f32(acc, M, E, ldx=E, ldo=E, out=x, resid=pos_full, ldr=E)
-        y32 = ws.f32('x_ln', M, E)
-        yh, yl = ws.bf16('x_ln_hi', M, E), ws.bf16('x_ln_lo', M, E)
-        hh, hl = ws.bf16('x_h_hi', M, Hd), ws.bf16('x_h_lo', M, Hd)
-        ao = ws.f32('x_ao', M, E)
+        plan.gemm(col, wp('patch_embed.proj.weight'), x, M, E, self.Kpe, ldx=2 * self.Kpe, ldy=2 * self.Kpe, ldo=E,
+                  epilogue=RES, bias=self.w('patch_embed.proj.bias'), pos=self.pos_comb, pos_rows=T, split3=True)
+        y = ws.bf16('x_ln_pair', M, 2 * E)
+        qkv = ws.f32('x_qkv', M, 3 * E)
+        ao = ws.bf16('x_ao_pair', M, 2 * E)
+        hh = ws.bf16('x_h_pair', M, 2 * Hd)
+        route2 = None
         for i in range(self.depth):
             b = f'blocks.{i}.'
-            plan.layernorm_fwd(x, self.w(b + 'norm1.weight'), self.w(b + 'norm1.bias'), None, y32, None, None, M, E)
-            plan.split_f32(y32, yh, yl, None, M * E)
-            plan.gemm3(yh, yl, self.h(b + 'attn.qkv.weight'), wl(b + 'attn.qkv.weight'), acc, M, 3 * E, E,
-                       ldx=E, ldy=E, ldo=3 * E,
-                       bias=self.w(b + 'attn.qkv.bias') if self.has(b + 'attn.qkv.bias') else None)
-            plan.attention_f32(acc, ao, B, self.heads, self.d, T, self.scale)
-            plan.split_f32(ao, yh, yl, None, M * E)
-            plan.gemm3(yh, yl, self.h(b + 'attn.proj.weight'), wl(b + 'attn.proj.weight'), acc, M, E, E,
-                       ldx=E, ldy=E, ldo=E, bias=self.w(b + 'attn.proj.bias'))
-            plan.finish_f32(acc, M, E, ldx=E, ldo=E, out=xm, resid=x, ldr=E)
-            plan.layernorm_fwd(xm, self.w(b + 'norm2.weight'), self.w(b + 'norm2.bias'), None, y32, None, None, M, E)
-            plan.split_f32(y32, yh, yl, None, M * E)
-            plan.gemm3(yh, yl, self.h(b + 'mlp.fc1.weight'), wl(b + 'mlp.fc1.weight'), acc, M, Hd, E,
-                       ldx=E, ldy=E, ldo=Hd, bias=self.w(b + 'mlp.fc1.bias'))
-            plan.finish_f32(acc, M, Hd, ldx=Hd, ldo=Hd, hi=hh, lo=hl, act=1)
-            plan.gemm3(hh, hl, self.h(b + 'mlp.fc2.weight'), wl(b + 'mlp.fc2.weight'), acc, M, E, Hd,
-                       ldx=Hd, ldy=Hd, ldo=E, bias=self.w(b + 'mlp.fc2.bias'), route=self._route(ws, B, i))
-            plan.finish_f32(acc, M, E, ldx=E, ldo=E, out=x, resid=xm, ldr=E)
-        feat = ws.f32('x_feat', M, E)
+            plan.layernorm_fwd_pair(x, self.w(b + 'norm1.weight'), self.w(b + 'norm1.bias'), y, M, E)
+            plan.gemm(y, wp(b + 'attn.qkv.weight'), qkv, M, 3 * E, E, ldx=2 * E, ldy=2 * E, ldo=3 * E, epilogue=F32,
+                      bias=self.w(b + 'attn.qkv.bias') if self.has(b + 'attn.qkv.bias') else None, split3=True)
+            plan.attention_split(qkv, ao, B, self.heads, self.d, T, self.scale)
+            plan.gemm(ao, wp(b + 'attn.proj.weight'), xm, M, E, E, ldx=2 * E, ldy=2 * E, ldo=E, epilogue=RES,
+                      bias=self.w(b + 'attn.proj.bias'), resid=x, split3=True)
+            plan.layernorm_fwd_pair(xm, self.w(b + 'norm2.weight'), self.w(b + 'norm2.bias'), y, M, E)
+            plan.gemm(y, wp(b + 'mlp.fc1.weight'), hh, M, Hd, E, ldx=2 * E, ldy=2 * E, ldo=2 * Hd, epilogue=PAIR,
+                      pair_act=1, bias=self.w(b + 'mlp.fc1.bias'), split3=True)
+            if self.part:
+                # expert rows sit `delta` elements behind the shared matrix in the flat buffers: twice that in the pair array
+                expert = self.route_buffers(ws, B)[0]
+                route2 = (expert, self.moe_delta[i] * 2, self.moe_bdelta[i], self.E - self.part)
+            plan.gemm(hh, wp(b + 'mlp.fc2.weight'), x, M, E, Hd, ldx=2 * Hd, ldy=2 * Hd, ldo=E, epilogue=RES,
+                      bias=self.w(b + 'mlp.fc2.bias'), resid=xm, split3=True, route=route2)
+        feat = ws.bf16('x_feat_pair', M, 2 * E)
         if self.cfg.get('last_norm', True):
-            plan.layernorm_fwd(x, self.w('last_norm.weight'), self.w('last_norm.bias'), None, feat, None, None, M, E)
+            plan.layernorm_fwd_pair(x, self.w('last_norm.weight'), self.w('last_norm.bias'), feat, M, E, relu=relu_out)
         else:
-            plan.strided_cast(x, feat, (1, 1, 1, M * E), (0, 0, 0, 1))
+            raise NotImplementedError('last_norm=False in the fp32-accurate path')
         return feat
 
     # -- backward (training workspaces of record_forward(training=True) required) --

@@ -174,71 +174,74 @@ class HeadRunner:
         bf, b = self.bf, self.w('final_layer.bias')
         plan.host(lambda: bf[:b.numel()].copy_(b))
 
-    # -- fp32-accurate evaluation: lo halves of the compute-layout weights + the forward pass --
+    # -- fp32-accurate evaluation: pair arrays of the compute-layout weights + the forward pass --
     def record_weight_prep_exact(self, plan: Plan):
-        """bf16(w - bf16(w)) in the layouts of record_weight_prep (store.data_lo must be current)."""
+        """hi / lo pair arrays of the re-laid-out weights of record_weight_prep, built from the f32 masters."""
         dev = self.store.device
-        lf = lambda n: self.store.lfview(self.pre + n)
+        f32 = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         if self.simple:
-            self.wcat_lo = torch.zeros_like(self.wcat)
-            W = lf('final_layer.weight')
+            self._wcat32 = f32(self.ngp, self.cin)
+            self.wcat_pair = torch.zeros(self.ngp, 2 * self.cin, dtype=torch.bfloat16, device=dev)
+            W = self.w('final_layer.weight')
             for t in range(self.taps):
-                plan.strided_cast(W.view(-1)[t:], self.wcat_lo[t * self.kp:], (1, 1, self.K, self.cin),
+                plan.strided_cast(W.view(-1)[t:], self._wcat32[t * self.kp:], (1, 1, self.K, self.cin),
                                   (0, 0, self.cin * self.taps, self.taps))
+            plan.split_pair(self._wcat32, self.wcat_pair, self._wcat32.numel())
             return
-        self.wph_lo = [torch.empty_like(w) for w in self.wph]
+        self._wph32 = [f32(4, self.chans[l + 1], 4 * self.chans[l]) for l in range(self.nl)]
+        self.wph_pair = [torch.zeros(4, self.chans[l + 1], 8 * self.chans[l], dtype=torch.bfloat16, device=dev)
+                         for l in range(self.nl)]
         for l in range(self.nl):
-            W = lf(f'deconv_layers.{3 * l}.weight')
+            W = self.w(f'deconv_layers.{3 * l}.weight')
             ci, co = self.chans[l], self.chans[l + 1]
             for py in range(2):
                 for px in range(2):
+                    # wph[phase][co][(ty, tx, ci)] = W[ci][co][(1 - py) + 2 ty][(1 - px) + 2 tx]
                     src = W.view(-1)[(1 - py) * 4 + (1 - px):]
-                    plan.strided_cast(src, self.wph_lo[l][py * 2 + px], (co, 2, 2, ci), (16, 8, 2, co * 16))
-        self.wf_lo = torch.zeros_like(self.wf)
-        Wf = lf('final_layer.weight')
-        plan.strided_cast(Wf, self.wf_lo, (1, 1, 1, Wf.numel()), (0, 0, 0, 1))
+                    plan.strided_cast(src, self._wph32[l][py * 2 + px], (co, 2, 2, ci), (16, 8, 2, co * 16))
+            plan.split_pair(self._wph32[l], self.wph_pair[l], self._wph32[l].numel())
+        cl = self.chans[-1]
+        self._wf32 = f32(self.kpad, cl)
+        self.wf_pair = torch.zeros(self.kpad, 2 * cl, dtype=torch.bfloat16, device=dev)
+        Wf = self.w('final_layer.weight')
+        plan.strided_cast(Wf, self._wf32, (1, 1, 1, Wf.numel()), (0, 0, 0, 1))
+        plan.split_pair(self._wf32, self.wf_pair, self._wf32.numel())
 
-    def record_forward_exact(self, plan: Plan, ws: Workspace, feat32: torch.Tensor, B: int, heat_nchw: torch.Tensor):
-        """feat32: f32 channels-last [B*Hg*Wg][Cin]; eval-mode BatchNorm; writes heat_nchw f32."""
+    def record_forward_exact(self, plan: Plan, ws: Workspace, feat_pair: torch.Tensor, B: int, heat_nchw: torch.Tensor):
+        """feat_pair: hi / lo pair array [B*Hg*Wg][2 Cin] of the feature map (of its ReLU for the simple decoder
+        with `upsample`); eval-mode BatchNorm; writes heat_nchw f32."""
         H, W = self.Hg, self.Wg
         M0 = B * H * W
-        ah, al = ws.bf16('xh_a_hi', M0, self.cin), ws.bf16('xh_a_lo', M0, self.cin)
         if self.simple:
-            plan.finish_f32(feat32, M0, self.cin, ldx=self.cin, ldo=self.cin, hi=ah, lo=al,
-                            act=2 if self.upsample > 0 else 0)
             G = ws.f32('xh_G', M0, self.ng)
-            plan.gemm3(ah, al, self.wcat, self.wcat_lo, G, M0, self.ng, self.cin, ldx=self.cin, ldy=self.cin,
-                       ldo=self.ng)
+            plan.gemm(feat_pair, self.wcat_pair, G, M0, self.ng, self.cin, ldx=2 * self.cin, ldy=2 * self.cin,
+                      ldo=self.ng, epilogue=_lib.VP_EPI_F32, split3=True)
             plan.upconv_fwd(G, self.ng, self.w('final_layer.bias'), heat_nchw, self.tabs, B, self.K, self.kp,
                             self.Hg, self.Wg, self.Ho, self.Wo, self.fk)
             return
-        plan.split_f32(feat32, ah, al, None, M0 * self.cin)
+        a = feat_pair
         for l in range(self.nl):
             ci, co = self.chans[l], self.chans[l + 1]
-            Min, Mout = B * H * W, B * 4 * H * W
-            colh, coll = ws.bf16('xh_col_hi', Min * 4 * ci), ws.bf16('xh_col_lo', Min * 4 * ci)
-            acc = ws.f32('xh_acc', Min * co)
-            zh, zl = ws.bf16(f'xh_z{l}_hi', Mout, co), ws.bf16(f'xh_z{l}_lo', Mout, co)
+            Mout = B * 4 * H * W
+            z = ws.bf16(f'xh_z{l}_pair', Mout, 2 * co)
             bn = f'deconv_layers.{3 * l + 1}.'
             plan.bn_finalize(None, Mout, co, self.w(bn + 'weight'), self.w(bn + 'bias'),
                              self.buf(bn + 'running_mean'), self.buf(bn + 'running_var'), 0.1, 1e-5,
                              self.bn_scale[l], self.bn_shift[l], None, None)
-            for py in range(2):
-                for px in range(2):
-                    ph = py * 2 + px
-                    plan.deconv_phase_im2col(ah, colh, B, H, W, ci, py, px)
-                    plan.deconv_phase_im2col(al, coll, B, H, W, ci, py, px)
-                    plan.gemm3(colh, coll, self.wph[l][ph], self.wph_lo[l][ph], acc, Min, co, 4 * ci,
-                               ldx=4 * ci, ldy=4 * ci, ldo=co)
-                    plan.finish_f32(acc, Min, co, ldx=co, ldo=co, hi=zh, lo=zl, colscale=self.bn_scale[l],
-                                    colshift=self.bn_shift[l], act=2, row_map=(W, 4 * W, 2, py * 2 * W + px))
-            ah, al = zh, zl
+            plan.deconv_fwd_split(a, self.wph_pair[l], z, B, H, W, ci, co, self.bn_scale[l], self.bn_shift[l])
+            a = z
             H, W = 2 * H, 2 * W
         Mh = B * H * W
         cl = self.chans[-1]
         heat = ws.f32('xh_heat_cl', Mh, self.kpad)
-        plan.gemm3(ah, al, self.wf, self.wf_lo, heat, Mh, self.kpad, cl, ldx=cl, ldy=cl, ldo=self.kpad, bias=self.bf)
+        plan.gemm(a, self.wf_pair, heat, Mh, self.kpad, cl, ldx=2 * cl, ldy=2 * cl, ldo=self.kpad,
+                  epilogue=_lib.VP_EPI_F32, bias=self.bf, split3=True)
         plan.heatmap_loss(heat, self.kpad, heat_nchw, None, None, None, None, B, self.K, H * W, 1.0)
+
+    @property
+    def exact_relu_input(self):
+        """The fp32-accurate plan feeds this head the ReLU of the feature map (simple decoder with `upsample`)."""
+        return bool(self.simple and self.upsample > 0)
 
     # -- forward --
     def record_forward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, B: int, training: bool,

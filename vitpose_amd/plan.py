@@ -199,12 +199,17 @@ class Plan:
     def gemm(self, x, y, out, M, N, K, *, ldx, ldy, ldo, x_kmajor=False, y_kmajor=False,
              epilogue=_lib.VP_EPI_BF16, out2=None, bias=None, colscale=None, resid=None,
              rowscale=None, rows_per_scale=0, aux=None, ldaux=0, pos=None, pos_rows=0, split_k=1,
-             row_map=None, split_stride=0, tail_force=False, tile_mode=0, route=None, gather16=None):
+             row_map=None, split_stride=0, tail_force=False, tile_mode=0, route=None, gather16=None,
+             split3=False, pair_act=0):
         """gather16 = (H, W, C): y is a transposed conv's output-grid gradient [B*2H*2W][C] and the Y operand its
         reduction-major 16-tap gather (see vp_gemm_args in the header).
         route = (expert [images] int32, delta [experts] int64, bias_delta [experts] int64 or None, split):
-        per-image routing of the Y operand (mixture-of-experts FFN; see vp_gemm_args in the header)."""
+        per-image routing of the Y operand (mixture-of-experts FFN; see vp_gemm_args in the header).
+        split3: x and y are hi / lo pair arrays (rows of 2 K bf16) and the product is fp32-accurate (hi*hi + hi*lo +
+        lo*hi per K step in one launch); epilogue VP_EPI_F32 / VP_EPI_RESID_F32 / VP_EPI_PAIR (out = pair array of
+        act(acc * colscale + bias), pair_act 0 none / 1 exact GELU / 2 ReLU)."""
         a = GemmArgs()
+        a.split3, a.pair_act = int(split3), int(pair_act)
         if gather16 is not None:
             zero = _zero_page(out.device)
             a.gather16_H, a.gather16_W, a.gather16_C = gather16
@@ -218,7 +223,7 @@ class Plan:
             a.route_expert, a.route_delta, a.route_split = r_exp.data_ptr(), r_delta.data_ptr(), int(r_split)
             a.route_bias_delta = r_bdelta.data_ptr() if r_bdelta is not None else None
             self.keep.extend(t for t in (r_exp, r_delta, r_bdelta) if t is not None)
-            tile_mode = 3
+            tile_mode = 0 if split3 else 3
         a.tail_force = int(tail_force)
         a.tile_mode = int(tile_mode)
         a.split_stride = split_stride
@@ -233,13 +238,14 @@ class Plan:
         a.rows_per_scale, a.ldaux, a.pos_rows, a.split_k = rows_per_scale, ldaux, pos_rows, split_k
         if row_map is not None:
             a.out_row_div, a.out_row_hi, a.out_row_lo, a.out_row_off = row_map
-        if self.use_tail_split and epilogue != _lib.VP_EPI_SPLITK_F32:
+        if self.use_tail_split and epilogue != _lib.VP_EPI_SPLITK_F32 and not split3:
             tw = _tail_workspace(out.device)
             a.tail_ws, a.tail_ws_bytes = tw.data_ptr(), tw.numel() * 4
             self.keep.append(tw)
-        if AUTOTUNE and tile_mode == 0 and epilogue != _lib.VP_EPI_SPLITK_F32 and M >= 512 and N >= 256 and K >= 256:
+        if (AUTOTUNE and tile_mode == 0 and epilogue != _lib.VP_EPI_SPLITK_F32 and M >= 512 and N >= 256 and K >= 256
+                and route is None):
             key = ('gemm', M, N, K, int(x_kmajor), int(y_kmajor), epilogue, resid is not None, out2 is not None,
-                   str(out.device))
+                   str(out.device), int(split3), int(pair_act))
             if key not in _TUNE_CACHE:
                 fn = self.L.vp_gemm_bf16
                 s_ = c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -251,7 +257,8 @@ class Plan:
                     return f
                 _TUNE_CACHE[key] = _pick_fastest({m: launch(m) for m in ((1, 2, 3) if x_kmajor else (1, 2, 3, 4))})
             a.tile_mode = _TUNE_CACHE[key]
-        self.tags[len(self.calls)] = (int(x_kmajor), int(y_kmajor), epilogue, M, N, K)
+        self.tags[len(self.calls)] = (int(x_kmajor), int(y_kmajor), epilogue + (200 if split3 else 0), M, N,
+                                      3 * K if split3 else K)
         self._add('vp_gemm_bf16', ctypes.byref(a),
                   keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
 
@@ -399,35 +406,29 @@ class Plan:
         _chk(img, torch.float32, 'img')
         self._add('vp_patch_im2col', _p(img), _p(col), B, C, H, W, patch, stride, pad, keep=(img, col))
 
-    # -- fp32-accurate path (hi / lo bf16 operand pairs) --
-    def gemm3(self, xh, xl, wh, wl, acc, M, N, K, *, ldx, ldy, ldo, bias=None, route=None):
-        """acc (f32) = x w^T + bias with x = xh + xl, w = wh + wl: three MFMA GEMMs chained through
-        the f32 accumulate epilogue (the lo * lo term, ~2^-16 relative, is dropped)."""
-        self.gemm(xh, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_F32, bias=bias, route=route)
-        nb = (route[0], route[1], None, route[3]) if route is not None else None   # the bias is added once
-        self.gemm(xh, wl, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc, route=nb)
-        self.gemm(xl, wh, acc, M, N, K, ldx=ldx, ldy=ldy, ldo=ldo, epilogue=_lib.VP_EPI_RESID_F32, resid=acc, route=nb)
+    # -- fp32-accurate path (hi / lo pair arrays; the products are gemm(..., split3=True)) --
+    def split_pair(self, x, pair, n):
+        _chk(x, torch.float32, 'x'), _chk(pair, torch.bfloat16, 'pair')
+        assert pair.numel() >= 2 * n
+        self._add('vp_split_pair_f32', _p(x), _p(pair), n, keep=(x, pair))
 
-    def finish_f32(self, x, M, N, *, ldx, ldo, out=None, hi=None, lo=None, colscale=None, colshift=None, act=0,
-                   resid=None, ldr=0, rowscale=None, rows_per_scale=0, row_map=None):
-        _chk(x, torch.float32, 'x')
-        rm = (ctypes.c_int * 4)(*row_map) if row_map is not None else None
-        self._add('vp_finish_f32', _p(x), ldx, _p(colscale), _p(colshift), act, _p(resid), ldr, _p(rowscale),
-                  rows_per_scale, _p(out), _p(hi), _p(lo), ldo, M, N, ctypes.byref(rm) if rm is not None else None,
-                  keep=(x, colscale, colshift, resid, rowscale, out, hi, lo, rm))
+    def layernorm_fwd_pair(self, x, gamma, beta, y_pair, M, E, relu=False, y_f32=None, eps=1e-6):
+        _chk(x, torch.float32, 'x'), _chk(y_pair, torch.bfloat16, 'y_pair')
+        self._add('vp_layernorm_fwd_pair', _p(x), _p(gamma), _p(beta), _p(y_pair), _p(y_f32), int(relu), M, E, eps,
+                  keep=(x, gamma, beta, y_pair, y_f32))
 
-    def split_f32(self, x, hi, lo, lo_f32, n):
-        _chk(x, torch.float32, 'x')
-        self._add('vp_split_f32', _p(x), _p(hi), _p(lo), _p(lo_f32), n, keep=(x, hi, lo, lo_f32))
+    def attention_split(self, qkv, out_pair, B, H, d, tokens, scale):
+        _chk(qkv, torch.float32, 'qkv'), _chk(out_pair, torch.bfloat16, 'out_pair')
+        self._add('vp_attention_split', _p(qkv), _p(out_pair), B, H, d, tokens, scale, keep=(qkv, out_pair))
 
-    def attention_f32(self, qkv, out, B, H, d, tokens, scale):
-        _chk(qkv, torch.float32, 'qkv')
-        self._add('vp_attention_f32', _p(qkv), _p(out), B, H, d, tokens, scale, keep=(qkv, out))
+    def patch_im2col_pair(self, img, col_pair, B, C, H, W, patch, stride, pad):
+        _chk(img, torch.float32, 'img'), _chk(col_pair, torch.bfloat16, 'col_pair')
+        self._add('vp_patch_im2col_pair', _p(img), _p(col_pair), B, C, H, W, patch, stride, pad, keep=(img, col_pair))
 
-    def patch_im2col_split(self, img, col_hi, col_lo, B, C, H, W, patch, stride, pad):
-        _chk(img, torch.float32, 'img')
-        self._add('vp_patch_im2col_split', _p(img), _p(col_hi), _p(col_lo), B, C, H, W, patch, stride, pad,
-                  keep=(img, col_hi, col_lo))
+    def deconv_fwd_split(self, src_pair, wph_pair, out_pair, B, H, W, C, Cout, colscale, shift):
+        zero = _zero_page(src_pair.device)
+        self._add('vp_deconv_fwd_split', _p(src_pair), _p(wph_pair), _p(out_pair), B, H, W, C, Cout, _p(colscale),
+                  _p(shift), _p(zero), keep=(src_pair, wph_pair, out_pair, colscale, shift, zero))
 
     def strided_cast(self, src, dst, dims, strides):
         dt = {torch.float32: _lib.VP_F32, torch.bfloat16: _lib.VP_BF16}

@@ -54,7 +54,8 @@ class PoseEngine:
         for h in self.heads:
             h.record_weight_prep(self.prep)
             h.record_weight_prep(self.prep_derived)
-        self.prep_exact = None      # lo halves of the weights, built on the first exact evaluation
+        self.prep_exact = None      # pair arrays of the weights, built on the first exact evaluation
+        self._weights_version, self._exact_version = 0, None
         self.optimizer = None
         self.comm = None
         # VITPOSE_SIDE_STREAM=1 puts the weight-gradient launches on a second HIP stream.  Off by default:
@@ -88,6 +89,7 @@ class PoseEngine:
         return out
 
     def refresh_weights(self, after_optimizer_step: bool = False):
+        self._weights_version += 1
         (self.prep_derived if after_optimizer_step else self.prep).run()
         self.vit.refresh_derived()
 
@@ -107,21 +109,21 @@ class PoseEngine:
         return self.plans[key]
 
     def _exact_plan(self, B):
-        """fp32-accurate evaluation (three bf16 MFMA GEMMs per Linear / conv on hi + lo operand pairs,
-        everything else in f32): parity with the reference's fp32 forward at ~1e-5 relative, ~4x the cost."""
+        """fp32-accurate evaluation (one split3 GEMM per Linear / conv on hi + lo pair operands, everything else in
+        f32): parity with the reference's fp32 forward at ~1e-5 relative."""
         key = ('exact', B)
         if key not in self.plans:
             if self.prep_exact is None:
-                self.store.ensure_lo()
+                self.store.ensure_pair()
                 self.prep_exact = Plan()
-                self.prep_exact.split_f32(self.store.data, None, self.store.half_lo, self.store.data_lo,
-                                          self.store.numel)
+                self.prep_exact.split_pair(self.store.data, self.store.pair, self.store.numel)
                 self.head.record_weight_prep_exact(self.prep_exact)
+                self._exact_version = None
             ws = self.ws_infer
             H, W = self.vit.img_hw
             img = ws.f32('img', B, self.vit.C, H, W)
             plan = Plan()
-            feat = self.vit.record_forward_exact(plan, ws, img, B)
+            feat = self.vit.record_forward_exact(plan, ws, img, B, relu_out=self.head.exact_relu_input)
             oh, ow = self.head.out_grid
             heat = ws.f32('heat', B, self.K, oh, ow)
             self.head.record_forward_exact(plan, ws, feat, B, heat)
@@ -140,8 +142,9 @@ class PoseEngine:
         plan, img_in, heat = self._exact_plan(B) if exact else self._infer_plan(B)
         if self.routed:
             self.vit.set_routing(self.ws_infer, B, dataset_source if dataset_source is not None else [0] * B)
-        if exact:
-            self.prep_exact.run()
+        if exact and self._exact_version != self._weights_version:
+            self.prep_exact.run()               # the pair arrays follow the f32 masters (refresh_weights bumps the version)
+            self._exact_version = self._weights_version
         if img.data_ptr() != img_in.data_ptr():
             img_in.copy_(img)
         plan.run()
