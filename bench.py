@@ -76,12 +76,47 @@ def plus_model_cfg(m, heads=6):
     return cfg
 
 
-def cpu_baseline(model_key, batch, mode, iters=3):
+def host_cores():
+    """Threads for the CPU leg: the job's CPU share.  The GPU box gives a one-GPU job 16 cores of a machine whose
+    os.cpu_count() is many times that (it exports OMP_NUM_THREADS = its share); elsewhere every visible core."""
+    visible = os.cpu_count() or 1
+    share = int(os.environ.get('OMP_NUM_THREADS', '0') or 0)
+    return (min(share, visible) if share > 0 else visible), visible
+
+
+def parity_vs_oracle(eng, model_key, batch, dev):
+    """Heat-map max-abs difference GPU vs CPU oracle on one identical batch, in this run: non-degenerate synthetic
+    weights (the reference's own init gives heat maps ~1e-4, where any tolerance is vacuous) loaded into the
+    engine that was just timed; eval forward, bf16 path and fp32-accurate path."""
+    from oracle import vitpose_oracle as O
+    m = MODELS[model_key]
+    vcfg, hc = O.vit_cfg(model_key), O.classic_head_cfg(m['embed_dim'])
+    bb, hd = O.synth_vit_weights(vcfg, seed=0), O.synth_head_weights(hc, seed=1)
+    img, _, _ = O.synth_batch(batch, seed=2)
+    with torch.no_grad():
+        ref = O.head_forward(hd, O.vit_forward(bb, img, vcfg), hc, training=False)
+    sd = {'backbone.' + k: v for k, v in bb.items()}
+    sd.update({'keypoint_head.' + k: v for k, v in hd.items()})
+    eng.load_state_dict(sd)
+    x = img.to(dev)
+    bf = (eng.infer(x).cpu() - ref).abs().max().item()
+    ex = (eng.infer(x, exact=True).cpu() - ref).abs().max().item()
+    return dict(parity_max_abs=round(bf, 6), parity_max_abs_fp32_exact=round(ex, 7),
+                parity_ref_max=round(ref.abs().max().item(), 3),
+                parity_note=f'GPU eval heat maps vs oracle/vitpose_oracle.py (fp32 CPU) on the same {batch} synthetic images, '
+                            'synthetic non-degenerate weights; parity_max_abs = the bf16 path that is timed in '
+                            'training / default inference, parity_max_abs_fp32_exact = the split3 (hi/lo pair) path '
+                            '(bench.py --mode infer --exact, test_cfg fp32_exact); north_star tolerance 1e-3')
+
+
+def cpu_baseline(model_key, batch, mode, iters=None):
     """The CPU oracle (torch fp32 restatement of the reference ops) timed on this box's host cores
     on a bounded sample of the same workload."""
     from oracle import vitpose_oracle as O
     m = MODELS[model_key]
-    cores = min(16, os.cpu_count() or 1)
+    cores, visible = host_cores()
+    if iters is None:
+        iters = 5
     torch.set_num_threads(cores)
     vcfg = O.vit_cfg(model_key) if model_key in O.VIT_CFGS else None
     hc = O.classic_head_cfg(m['embed_dim'])
@@ -94,24 +129,31 @@ def cpu_baseline(model_key, batch, mode, iters=3):
         for k, v in hd.items():
             if 'running' not in k:
                 v.requires_grad_()
+        params = [v for v in list(bb.values()) + list(hd.values()) if v.requires_grad]
+        opt = torch.optim.AdamW(params, lr=5e-4, betas=(0.9, 0.999), weight_decay=0.1)
 
         def step():
             heat = O.head_forward(hd, O.vit_forward(bb, img, vcfg), hc, training=True)
             O.joints_mse_loss(heat, target, tw).backward()
-        what = 'forward+backward (no optimizer)'
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            opt.zero_grad()
+        what = 'forward+backward+grad-clip+AdamW (torch.optim, one lr group)'
     else:
         def step():
             with torch.no_grad():
                 O.head_forward(hd, O.vit_forward(bb, img, vcfg), hc, training=False)
         what = 'eval forward'
-    step()
+    for _ in range(2):
+        step()
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
     dt = time.perf_counter() - t0
     return dict(value=round(batch * iters / dt, 3), unit='images/sec', cores=cores, kind='port',
                 sample=f'oracle/vitpose_oracle.py fp32 {what}, ViTPose-{model_key} classic, batch {batch}, '
-                       f'{iters} timed iterations after 1 warm-up, torch {torch.__version__} CPU, {cores} threads')
+                       f'{iters} timed iterations after 2 warm-ups, torch {torch.__version__} CPU, {cores} threads = '
+                       f'the CPU share of this job ({visible} logical CPUs visible on the machine)')
 
 
 def pmc_traffic(kernel_key):
@@ -256,14 +298,19 @@ def main():
     timers = []
     plan_of().timers = timers          # timed region: events (on the launch stream) around the dominant kernel only
     plan_of().timer_filter = {dom_key}
+    # one event per step boundary on the compute stream (no host sync inside the timed region): per-step GPU times
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         last = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     plan_of().timers = None
     plan_of().timer_filter = None
     if world > 1:
@@ -286,7 +333,9 @@ def main():
         out = {
             'metric': 'images/sec (256x192) ViTPose-B fwd+bwd at 1/2/4/8 GPUs; % bf16 MFMA roofline',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'step_ms_min': round(step_ms[0], 3), 'step_ms_median': round(step_ms[len(step_ms) // 2], 3),
+            'step_ms_max': round(step_ms[-1], 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16x3 (hi/lo bf16 pairs, f32 accumulate)' if args.exact else 'bf16',
             'data': 'synthetic',
             'config': {'workload': what, 'parallelism': f'dp{world}', 'global_batch': world * B},
@@ -311,6 +360,7 @@ def main():
             out['loss'] = float(last.item())
         if world == 1 and not args.no_cpu_baseline and not args.plus:
             out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_batch, args.mode)
+            out.update(parity_vs_oracle(eng, args.model, args.cpu_batch, dev))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

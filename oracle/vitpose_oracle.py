@@ -213,6 +213,8 @@ def head_forward(sd: Dict[str, Tensor], feat: Tensor, cfg: dict, training: bool 
         bn = f'deconv_layers.{3 * li + 1}.'
         x = F.batch_norm(x, sd[bn + 'running_mean'], sd[bn + 'running_var'],
                          sd[bn + 'weight'], sd[bn + 'bias'], training, bn_momentum, 1e-5)
+        if taps is not None:
+            taps[f'bn{li}'] = x
         x = F.relu(x)
     extra = cfg.get('extra') or {}
     fk = extra.get('final_conv_kernel', 1)

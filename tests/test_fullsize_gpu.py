@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import meas
+
 from oracle import vitpose_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -61,18 +63,19 @@ def test_full_size_train_step_vs_oracle(dev, setup):
     rl.backward()
     r_heat = rel(heat, ref.detach())
     print(f'full size: loss {loss.item():.6f} vs {rl.item():.6f}, heat rel {r_heat:.2e}')
-    assert r_heat < 3e-2
+    assert meas('fullsize heat rel', r_heat) < 1.1e-2
     assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
     worst = 0.0
     for n in ('blocks.11.mlp.fc2.weight', 'blocks.6.attn.qkv.weight', 'blocks.6.attn.qkv.bias', 'blocks.0.mlp.fc1.weight',
               'blocks.0.mlp.fc1.bias', 'blocks.0.norm1.weight', 'patch_embed.proj.weight', 'pos_embed', 'last_norm.bias'):
         r = rel(eng.store.gview('backbone.' + n), bbr[n].grad)
         worst = max(worst, r)
-        assert r < 0.12, (n, r)
+        # 64 images average the head's ReLU sign flips out: 1e-2 per tensor (4.3e-2 on the patch embedding)
+        assert meas(f'fullsize grad {n}', r) < (6.5e-2 if n.startswith('patch_embed') else 1.6e-2), (n, r)
     for n in ('final_layer.weight', 'deconv_layers.0.weight', 'deconv_layers.4.weight'):
         r = rel(eng.store.gview('keypoint_head.' + n), hdr[n].grad)
         worst = max(worst, r)
-        assert r < 0.12, (n, r)
+        assert meas(f'fullsize grad {n}', r) < 1.5e-2, (n, r)
     print(f'full size: worst per-tensor gradient rel err {worst:.2e}')
 
 
@@ -83,10 +86,10 @@ def test_full_size_eval_is_per_image_and_permutation_equivariant(dev, setup):
     full = eng.infer(img)
     # (a) an image's heat maps do not depend on its batch: batch 64 (large-tile schedules) vs batch 2
     small = eng.infer(img[:2])
-    assert rel(full[:2], small) < 1e-2
+    assert meas('fullsize batch 64 vs batch 2', rel(full[:2], small)) < 1e-3
     with torch.no_grad():
         ref = O.topdown_forward(s['bb'], s['hd'], s['img'][:2], s['vcfg'], s['hc'])
-    assert rel(small, ref) < 3e-2 and rel(full[:2], ref) < 3e-2
+    assert meas('fullsize eval rel (batch 2)', rel(small, ref)) < 9e-3 and meas('fullsize eval rel', rel(full[:2], ref)) < 9e-3
     # (b) permuting the batch permutes the output, exactly (same kernels, same tiles per row)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(dev)
     assert torch.equal(eng.infer(img[perm]), full[perm])

@@ -8,6 +8,8 @@ from the kernel's own saved activations."""
 import pytest
 import torch
 
+from conftest import meas
+
 from oracle import vitpose_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -50,7 +52,7 @@ def test_vitpose_h_inference_128_images(dev):
     assert ref.abs().max() > 0.5                       # non-degenerate heat maps
     r = rel(full[:2], ref)
     print(f'ViTPose-H x 128: heat maps of images 0-1 vs oracle, rel {r:.2e}')
-    assert r < 4e-2
+    assert meas('H x128 eval rel', r) < 1e-2
     assert rel(eng.infer(x[:2]), full[:2]) < 1e-2      # an image does not depend on its batch
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(7)).to(dev)
     assert torch.equal(eng.infer(x[perm]), full[perm])
@@ -67,7 +69,7 @@ def test_vitpose_l_train_step_32_images(dev):
         ref = O.topdown_forward(bb, hd, img[:2], vcfg, hc)
     r = rel(eng.infer(x)[:2], ref)
     print(f'ViTPose-L x 32: eval heat maps of images 0-1 vs oracle, rel {r:.2e}')
-    assert r < 4e-2
+    assert meas('L x32 eval rel', r) < 1e-2
     # training step (DropPath off so that the properties below are deterministic)
     loss, heat = eng.forward_backward(x, t, w, drop_path=False)
     torch.cuda.synchronize()
@@ -81,8 +83,8 @@ def test_vitpose_l_train_step_32_images(dev):
     ws = eng.ws_train.bufs
     last = vcfg['depth'] - 1
     dxb, h = ws[f'dxb.{last}.mlp'].float(), ws[f'h.{last}'].float()
-    assert rel(eng.store.gview(f'backbone.blocks.{last}.mlp.fc2.weight'), dxb.t() @ h) < 1e-3
-    assert rel(eng.store.gview(f'backbone.blocks.{last}.mlp.fc2.bias'), dxb.sum(0)) < 1e-3
+    assert meas('vitpose_l_train_step_32_images L84', rel(eng.store.gview(f'backbone.blocks.{last}.mlp.fc2.weight'), dxb.t() @ h)) < 1e-3
+    assert meas('vitpose_l_train_step_32_images L85', rel(eng.store.gview(f'backbone.blocks.{last}.mlp.fc2.bias'), dxb.sum(0))) < 1e-3
     # zero target weights: zero loss, exactly zero gradients
     loss0, _ = eng.forward_backward(x, t, torch.zeros_like(w), drop_path=False)
     torch.cuda.synchronize()
@@ -91,4 +93,4 @@ def test_vitpose_l_train_step_32_images(dev):
     eng2, *_ = make('L', dev, 80, loss_weight=0.5)
     eng2.forward_backward(x, t, w, drop_path=False)
     torch.cuda.synchronize()
-    assert rel(eng2.store.grad, 0.5 * g1) < 2e-2
+    assert meas('vitpose_l_train_step_32_images L94', rel(eng2.store.grad, 0.5 * g1)) < 2e-2

@@ -9,12 +9,20 @@ is asserted on the reference's own weight initialisation (trunc_normal 0.02 back
 std=0.001 head: heatmap magnitudes ~1e-4..1e-3).  On the non-degenerate synthetic
 weights of the golden fixtures (heatmaps O(1)) bf16 rounding gives ~1e-2 max-abs; that
 bound is asserted separately as a relative error so the number is visible.
+
+Every bound below is the value measured on an MI355X + 50 % (`meas` logs the values when VITPOSE_TEST_LOG is
+set).  Heat maps: 6e-3 relative.  Gradients of a model with the classic (deconv + BatchNorm + ReLU) head: 3 - 9 %
+per tensor, all of it from the ReLU masks of the head, which differ from the fp32 forward's on the 0.1 - 0.3 % of
+pre-activations that lie within bf16 rounding of zero (tests/test_grad_stages_gpu.py walks the backward pass stage
+by stage: no other stage adds more than 0.5 %); with the simple decoder the same gradients are within 0.5 %.
 """
 import os
 
 import numpy as np
 import pytest
 import torch
+
+from conftest import meas
 
 from oracle import vitpose_oracle as O
 
@@ -69,9 +77,9 @@ def test_toy_backbone_tokens(dev, golden_dir):
                              ('block_out', 'x_in.1', 64)):
         got = ws.bufs[buf].float().view(2, 192, width)[0].cpu()
         rel, mx = relerr(got, g[name][0])
-        assert rel < 1.5e-2, (name, rel, mx)
+        assert meas(f'toy fwd stage {name} rel', rel) < 6e-3, (name, rel, mx)
     rel, mx = relerr(feat, g['feat'])
-    assert rel < 2e-2, (rel, mx)
+    assert meas('toy fwd feat rel', rel) < 5e-3, (rel, mx)
 
 
 def test_vitpose_s_classic_eval_vs_reference_golden(dev, golden_dir):
@@ -83,7 +91,7 @@ def test_vitpose_s_classic_eval_vs_reference_golden(dev, golden_dir):
     assert heat.shape == (2, 17, 64, 48)
     rel, mx = relerr(heat, g['heat'])
     print(f'ViTPose-S classic eval, O(1) heatmaps (|ref|max {np.abs(g["heat"]).max():.2f}): rel {rel:.2e} maxabs {mx:.2e}')
-    assert rel < 3e-2 and mx < 0.15, (rel, mx)
+    assert meas('S classic eval rel', rel) < 9e-3 and meas('S classic eval maxabs', mx) < 5e-2, (rel, mx)
 
 
 def test_reference_init_heatmaps_within_1e3(dev):
@@ -137,8 +145,8 @@ def test_vitpose_s_train_step_vs_reference_golden(dev, golden_dir):
     torch.cuda.synchronize()
     rel, mx = relerr(heat[:, ::4], g['heat_sub'])
     print(f'train heat: rel {rel:.2e} max {mx:.2e}; loss {loss.item():.6f} vs {float(g["loss"]):.6f}')
-    assert rel < 3e-2
-    assert abs(loss.item() - float(g['loss'])) < 2e-2 * float(g['loss'])
+    assert meas('S train heat rel', rel) < 9e-3
+    assert meas('S train loss rel', abs(loss.item() - float(g['loss'])) / float(g['loss'])) < 1e-3
     worst = {}
     for k in g.files:
         if k.startswith('g.'):
@@ -153,12 +161,12 @@ def test_vitpose_s_train_step_vs_reference_golden(dev, golden_dir):
             continue
         worst[k] = relerr(got.reshape(g[k].shape), g[k])[0]
     print('grad rel errors:', {k: f'{v:.1e}' for k, v in worst.items()})
-    assert max(worst.values()) < 8e-2, worst
+    assert meas('S train worst grad rel', max(worst.values())) < 7.5e-2, worst
     # BN running statistics were updated with the batch statistics
     for n, k in (('deconv_layers.1.running_mean', 'bn1_mean'), ('deconv_layers.1.running_var', 'bn1_var'),
                  ('deconv_layers.4.running_mean', 'bn4_mean'), ('deconv_layers.4.running_var', 'bn4_var')):
         rel, _ = relerr(eng.buffers['keypoint_head.' + n], g[k])
-        assert rel < 2e-2, (n, rel)
+        assert meas(f'S train {n} rel', rel) < 2e-3, (n, rel)
 
 
 def test_train_step_updates_weights_like_torch_adamw(dev):
@@ -196,9 +204,9 @@ def test_train_step_updates_weights_like_torch_adamw(dev):
         den += d_ref.pow(2).sum().item()
     rel = (num / den) ** 0.5
     print(f'relative error of the first AdamW update over all parameters: {rel:.3e}')
-    # Adam's first update is lr * g / (|g| + eps): sign-like, so the 1-2 % bf16 gradient noise
-    # flips near-zero entries; 0.17 measured, a wrong gradient anywhere gives ~1.4
-    assert rel < 0.3
+    # Adam's first update is lr * g / (|g| + eps): sign-like, so the bf16 gradient noise flips near-zero entries;
+    # 0.17 measured, a wrong gradient anywhere gives ~1.4
+    assert meas('toy adamw first-update rel', rel) < 0.25
 
 
 def test_vitpose_s_simple_decoder_vs_reference_golden(dev, golden_dir):
@@ -212,7 +220,7 @@ def test_vitpose_s_simple_decoder_vs_reference_golden(dev, golden_dir):
     assert heat.shape == (1, 17, 64, 48)
     rel, mx = relerr(heat, g['heat'])
     print(f'ViTPose-S simple decoder, |ref|max {np.abs(g["heat"]).max():.2f}: rel {rel:.2e} maxabs {mx:.2e}')
-    assert rel < 3e-2, (rel, mx)
+    assert meas('S simple eval rel', rel) < 9e-3, (rel, mx)
 
 
 def test_simple_decoder_train_step_vs_oracle(dev):
@@ -228,12 +236,12 @@ def test_simple_decoder_train_step_vs_oracle(dev):
     ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), hc, training=True)
     rl = O.joints_mse_loss(ref, target, tw)
     rl.backward()
-    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert meas('toy simple train heat rel', relerr(heat, ref.detach())[0]) < 6e-3
     assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
     for n in ('final_layer.weight', 'final_layer.bias'):
-        assert relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0] < 5e-2, n
+        assert meas(f'toy simple grad {n}', relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0]) < 5e-3, n
     for n in ('blocks.1.mlp.fc2.weight', 'blocks.0.attn.qkv.weight', 'patch_embed.proj.weight', 'pos_embed'):
-        assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 8e-2, n
+        assert meas(f'toy simple grad {n}', relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0]) < 3.6e-2, n   # (patch embedding 2.4e-2: ReLU sign flips in front of the decoder; the rest 5e-3)
 
 
 @pytest.mark.parametrize('name', ['L', 'H'])
@@ -253,11 +261,11 @@ def test_large_and_huge_widths_one_block_train_step(dev, name):
     ref = O.head_forward(hdr, O.vit_forward(bbr, img, vcfg), hc, training=True)
     rl = O.joints_mse_loss(ref, target, tw)
     rl.backward()
-    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert meas('large_and_huge_widths_one_block_tra L256', relerr(heat, ref.detach())[0]) < 8e-3
     assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
     for n in ('blocks.0.attn.qkv.weight', 'blocks.0.attn.proj.weight', 'blocks.0.mlp.fc1.weight', 'blocks.0.norm1.weight',
               'patch_embed.proj.weight'):
-        assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 0.1, n
+        assert meas(f'large_and_huge_widths_one_block_tra {n}', relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0]) < 0.1, n
 
 
 # ---------------------------------------------------------------------------------------------
@@ -339,7 +347,7 @@ def test_ddp_plan_on_gpu_single_rank_group(dev):
         # loss reductions feed bf16 roundings downstream), so "same gradients" is a per-tensor norm bound
         for n in eng.store.names:
             got, ref = eng.store.gview(n), ref_eng.store.gview(n)
-            assert relerr(got, ref)[0] < 2e-2, n
+            assert meas(f'ddp_plan_on_gpu_single_rank_group {n}', relerr(got, ref)[0]) < 7e-3, n
     finally:
         if created:
             dist.destroy_process_group()
@@ -361,15 +369,15 @@ def test_wholebody_133_keypoints_train_step_and_eval(dev):
     ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), hc, training=True)
     rl = O.joints_mse_loss(ref, target, tw)
     rl.backward()
-    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert meas('wholebody_133_keypoints_train_step_ L364', relerr(heat, ref.detach())[0]) < 9e-3
     assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
     for n in ('final_layer.weight', 'final_layer.bias', 'deconv_layers.3.weight'):
-        assert relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0] < 0.12, n
-    assert relerr(eng.store.gview('backbone.blocks.1.mlp.fc2.weight'), bbr['blocks.1.mlp.fc2.weight'].grad)[0] < 0.12
+        assert meas(f'wholebody_133_keypoints_train_step_ {n}', relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0]) < 1.7e-2, n
+    assert meas('wholebody_133_keypoints_train_step_ L368', relerr(eng.store.gview('backbone.blocks.1.mlp.fc2.weight'), bbr['blocks.1.mlp.fc2.weight'].grad)[0]) < 3.7e-2
     with torch.no_grad():
         ref_eval = O.topdown_forward(bb, hd, img, TOY, hc)
     ev = make_engine(TOY, hc, bb, hd, dev)      # fresh BatchNorm running statistics (the train step moved eng's)
-    assert relerr(ev.infer(img.to(dev)), ref_eval)[0] < 3e-2
+    assert meas('wholebody_133_keypoints_train_step_ L372', relerr(ev.infer(img.to(dev)), ref_eval)[0]) < 8e-3
     assert (ev.infer(img.to(dev), exact=True).cpu() - ref_eval).abs().max().item() < 1e-3 * max(1.0, ref_eval.abs().max().item())
 
 
@@ -389,18 +397,18 @@ def test_odd_batch_sizes_train_and_eval_vs_oracle(dev, B):
     ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), hc, training=True)
     rl = O.joints_mse_loss(ref, target, tw)
     rl.backward()
-    assert relerr(heat, ref.detach())[0] < 3e-2
+    assert meas('odd_batch_sizes_train_and_eval_vs_o L392', relerr(heat, ref.detach())[0]) < 9e-3
     assert abs(loss.item() - rl.item()) < 3e-2 * rl.item()
     for n in ('blocks.1.mlp.fc2.weight', 'blocks.0.attn.qkv.weight', 'blocks.0.norm1.weight', 'pos_embed',
               'patch_embed.proj.weight', 'blocks.1.mlp.fc1.bias'):
-        assert relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0] < 0.12, n
+        assert meas(f'odd_batch_sizes_train_and_eval_vs_o {n}', relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0]) < 0.135, n
     for n in ('final_layer.weight', 'deconv_layers.0.weight', 'deconv_layers.3.weight', 'deconv_layers.4.bias'):
-        assert relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0] < 0.12, n
+        assert meas(f'odd_batch_sizes_train_and_eval_vs_o {n}', relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0]) < 7.2e-2, n
     with torch.no_grad():
         ref_eval = O.head_forward({k: v.detach() for k, v in hdr.items()},
                                   O.vit_forward({k: v.detach() for k, v in bbr.items()}, img, TOY), hc)
     # eval after one training pass: the engine's running statistics carry that pass's update, like the oracle's
-    assert relerr(eng.infer(img.to(dev)), ref_eval)[0] < 3e-2
+    assert meas('odd_batch_sizes_train_and_eval_vs_o L403', relerr(eng.infer(img.to(dev)), ref_eval)[0]) < 8e-3
 
 
 def test_empty_batch_is_rejected(dev):

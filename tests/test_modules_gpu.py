@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import meas
+
 from oracle import vitpose_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -124,21 +126,21 @@ def test_vit_module_forward_backward_vs_oracle(dev):
     bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
     ref = O.vit_forward(bbr, img, TOY)
     (ref * cot).sum().backward()
-    assert rel(out, ref) < 2e-2
+    assert meas('ViT module feature rel', rel(out, ref)) < 5e-3
     for n, p in vit.named_parameters():
         assert p.grad is not None, n
         assert rel(p.grad, bbr[n].grad) < 6e-2, (n, rel(p.grad, bbr[n].grad))
     # a second backward without zero_grad accumulates, as autograd does
     out2 = vit(img.to(dev))
     (out2 * cot.to(dev)).sum().backward()
-    assert rel(vit.blocks[0].attn.qkv.weight.grad, 2 * bbr['blocks.0.attn.qkv.weight'].grad) < 6e-2
+    assert meas('vit_module_forward_backward_vs_orac L134', rel(vit.blocks[0].attn.qkv.weight.grad, 2 * bbr['blocks.0.attn.qkv.weight'].grad)) < 7e-3
     # eval / no_grad path and an in-place weight change (picked up through the version counters)
     vit.eval()
     with torch.no_grad():
         o1 = vit(img.to(dev))
         vit.last_norm.bias.add_(1.0)
         o2 = vit(img.to(dev))
-    assert rel(o1, ref) < 2e-2 and abs((o2 - o1).mean().item() - 1.0) < 1e-2
+    assert rel(o1, ref) < 5e-3 and abs((o2 - o1).mean().item() - 1.0) < 1e-2
 
 
 @pytest.mark.parametrize('kind', ['classic', 'simple'])
@@ -168,7 +170,7 @@ def test_head_module_forward_backward_vs_oracle(dev, kind):
     for n, p in head.named_parameters():
         assert rel(p.grad, hdr[n].grad) < (0.1 if kind == 'classic' else 6e-2), n
     if kind == 'classic':   # running statistics updated in the module's own buffers
-        assert rel(head.deconv_layers[1].running_mean, hdr['deconv_layers.1.running_mean']) < 2e-2
+        assert meas('head_module_forward_backward_vs_ora L171', rel(head.deconv_layers[1].running_mean, hdr['deconv_layers.1.running_mean'])) < 2e-3
         assert int(head.deconv_layers[1].num_batches_tracked) == 1
     acc = head.get_accuracy(out, target.to(dev), tw.to(dev))
     ref_acc = O.pck_accuracy(out.detach().cpu().numpy(), target.numpy(), tw.numpy().squeeze(-1) > 0)[1]
@@ -232,7 +234,7 @@ def test_topdown_forward_test_flip_and_decode(dev, golden_dir):
                   flip_pairs=PAIRS, bbox_score=0.9) for i in range(2)]
     res = m(img=img.to(dev), img_metas=metas, return_loss=False, return_heatmap=True)
     assert set(res) == {'preds', 'boxes', 'image_paths', 'bbox_ids', 'output_heatmap'}
-    assert rel(res['output_heatmap'], g3['heat']) < 3e-2
+    assert meas('TopDown flip-test heat rel', rel(res['output_heatmap'], g3['heat'])) < 9e-3
     assert res['preds'].shape == (2, 17, 3) and res['boxes'].shape == (2, 6) and res['bbox_ids'] == [0, 1]
     # decode is host arithmetic on the heat maps: identical to the reference recipe applied to OUR maps
     hm = res['output_heatmap']
@@ -246,7 +248,7 @@ def test_topdown_forward_test_flip_and_decode(dev, golden_dir):
     with torch.no_grad():
         d = m.forward_dummy(img.to(dev))
     g1 = np.load(os.path.join(golden_dir, 'vitpose_s_classic_eval.npz'))
-    assert rel(d, g1['heat']) < 3e-2
+    assert meas('TopDown forward_dummy heat rel', rel(d, g1['heat'])) < 9e-3
 
 
 def test_topdown_forward_test_fp32_exact_1e3(dev, golden_dir):
