@@ -327,6 +327,22 @@ int vp_flip_back_avg(const float* heat, const float* heat_flipped, const int* pe
                      int N, int K, int H, int W, vp_stream_t stream);
 int vp_decode_heatmaps(const float* heat, float* preds, float* maxvals, int maps, int H, int W, int mode,
                        const float* taps_host, int ntaps, vp_stream_t stream);
+/* The remaining branches of keypoints_from_heatmaps, which blur whole maps (one workgroup per joint, maps in LDS):
+ *   mode 3: post_process='unbiased' (top_down_eval.py:591-597): arg-max of the map, then _gaussian_blur (:399-438:
+ *     cv2.GaussianBlur inside a zero border of (ntaps - 1) / 2, rescaled so that the maximum is restored),
+ *     log(max(., 1e-10)) and the second-order Taylor step of _taylor (:298-332) at the arg-max;
+ *   mode 4: post_process='megvii' (:563-564, :598-612, :619-620): _gaussian_blur first, arg-max of the modulated map,
+ *     +-0.25 shift and +0.5, maxvals = max / 255 + 0.5;
+ *   mode 5: UDP with target_type='CombinedTarget' (:571-585): heat = [joints][3][H][W] (heat map, x offset,
+ *     y offset per joint); the heat map is blurred with taps2 (2 * kernel + 1 taps), the offset maps with taps
+ *     (kernel taps), BORDER_REFLECT_101; preds = arg-max of the blurred heat map + valid_radius * blurred offsets
+ *     there (valid_radius = valid_radius_factor * H).  An invalid joint (maximum <= 0) reads the offsets at the
+ *     map corner (the reference's flat index goes negative there and wraps into another map).
+ * taps_host / taps2_host: HOST pointers to the 1-D blur kernels (copied into the kernel arguments).
+ * preds [joints][2] (x, y) in heat-map pixels, maxvals [joints]. */
+int vp_decode_blurred(const float* heat, float* preds, float* maxvals, int joints, int H, int W, int mode,
+                      const float* taps_host, int ntaps, const float* taps2_host, int ntaps2, float valid_radius,
+                      vp_stream_t stream);
 
 /* ----------------------------------------------------- fp32-accurate path ----------
  * Evaluation at the reference's fp32 accuracy (the 1e-3 max-abs heat-map tolerance on arbitrary weights; the

@@ -4,8 +4,8 @@ by tests/golden/make_golden.py for its input recipe, never by the product).
 Follows mmpose/core/evaluation/top_down_eval.py (`_get_max_preds` :63-95, `_taylor` :298-332,
 `post_dark_udp` :335-396, `_gaussian_blur` :399-438, `keypoints_from_heatmaps` :474-622) and
 mmpose/core/post_processing/post_transforms.py (`transform_preds` :150-194, `flip_back` :54-95), written
-map-by-map with explicit loops and scipy.ndimage for the blur, i.e. independently of the vectorised
-product code in vitpose_amd/models.py and of the HIP kernel.
+map-by-map with explicit loops and scipy.ndimage for the blur, i.e. independently of the HIP kernels that
+decode in the product (vitpose_amd/csrc/decode.hip).
 
 Pinning: tests/golden/decode.npz holds the outputs of the reference's own functions for post_process None /
 'default', `_taylor`, `transform_preds` and DARK-UDP with modulate kernel 1 (identity blur).  The blur itself
@@ -135,6 +135,28 @@ def keypoints_from_heatmaps(heatmaps, center, scale, post_process='default', ker
                         c = c + 0.5
             preds[n, k] = to_image(c, center[n], scale[n], W, H, use_udp) if image_space else c
             maxvals[n, k] = v / 255.0 + 0.5 if post_process == 'megvii' else v
+    return preds, maxvals
+
+
+def combined_target_decode(heatmaps, center, scale, kernel=11, valid_radius_factor=0.0546875, image_space=True):
+    """UDP decoding of 'CombinedTarget' maps (top_down_eval.py:571-585): three maps per joint (heat, x offset,
+    y offset); the heat map is blurred with 2 * kernel + 1 taps, the offsets with `kernel` taps; the arg-max of the
+    blurred heat map is moved by valid_radius_factor * H times the blurred offsets at that pixel."""
+    N, C, H, W = heatmaps.shape
+    K = C // 3
+    preds = np.zeros((N, K, 2), dtype=np.float32)
+    maxvals = np.zeros((N, K, 1), dtype=np.float32)
+    radius = np.float32(valid_radius_factor * H)
+    for n in range(N):
+        for k in range(K):
+            hm = blur(heatmaps[n, 3 * k].astype(np.float32), 2 * kernel + 1)
+            ox = blur(heatmaps[n, 3 * k + 1].astype(np.float32), kernel)
+            oy = blur(heatmaps[n, 3 * k + 2].astype(np.float32), kernel)
+            c, v = max_pred(hm)
+            x, y = int(c[0]), int(c[1])
+            c = c + np.array([ox[y, x] * radius, oy[y, x] * radius], dtype=np.float32)
+            preds[n, k] = to_image(c, center[n], scale[n], W, H, True) if image_space else c
+            maxvals[n, k] = v
     return preds, maxvals
 
 

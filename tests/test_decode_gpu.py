@@ -1,5 +1,6 @@
-"""Device-side decoding (vp_decode_heatmaps, vp_flip_back_avg through the C ABI) against the oracle, the
-reference-produced vectors, and the host path of the same model."""
+"""Device-side decoding (vp_decode_heatmaps, vp_decode_blurred, vp_flip_back_avg through the C ABI) against the
+oracle, the reference-produced vectors and the known answers of the reference's unit test.  The product decodes
+every post_process branch on the GPU; a host array is uploaded first."""
 import os
 
 import numpy as np
@@ -57,13 +58,91 @@ def test_device_decode_vs_reference_vectors_and_oracle(dev, gold):
 
 
 def test_reference_unit_case_on_device(dev):
-    from vitpose_amd.models import keypoints_from_heatmaps_device as dec
+    """tests/test_evaluation/test_top_down_eval.py:29-89 (test_keypoints_from_heatmaps), through the product's
+    keypoints_from_heatmaps on host arrays and on device tensors."""
+    from vitpose_amd.models import keypoints_from_heatmaps as f
+    hm = np.ones((1, 1, 64, 64), dtype=np.float32)
+    hm[0, 0, 31, 31] = 2
+    c, s = np.array([[127, 127]]), np.array([[64 / 200.0, 64 / 200.0]])
+    for x in (hm, torch.from_numpy(hm).to(dev)):
+        p, m = f(x, c, s)
+        np.testing.assert_array_almost_equal(p, np.array([[[126, 126]]]), decimal=4)
+        np.testing.assert_array_almost_equal(m, np.array([[[2]]]), decimal=4)
+        assert isinstance(p, np.ndarray) and isinstance(m, np.ndarray)
+        p, m = f(x, c, s, post_process='unbiased')
+        np.testing.assert_array_almost_equal(p, np.array([[[126, 126]]]), decimal=4)
+        np.testing.assert_array_almost_equal(m, np.array([[[2]]]), decimal=4)
+    assert hm[0, 0, 31, 31] == 2 and hm.sum() == 64 * 64 + 1            # the caller's array is not modified
     udp = np.ones((32, 17, 64, 64), dtype=np.float32)
     udp[:, :, 31, 31] = 2
-    p, m = dec(torch.from_numpy(udp).to(dev), np.tile([127, 127], (32, 1)), np.tile([32, 32], (32, 1)), mode=2,
-               kernel=11, use_udp=True)
+    p, m = f(udp, np.tile([127, 127], (32, 1)), np.tile([32, 32], (32, 1)), post_process='default', use_udp=True)
     np.testing.assert_array_almost_equal(p, np.tile([76, 76], (32, 17, 1)), decimal=0)
     np.testing.assert_array_almost_equal(m, np.tile([2], (32, 17, 1)), decimal=4)
+
+
+def test_blurred_branches_on_device_vs_oracle(dev, gold):
+    """post_process 'unbiased' (DARK) and 'megvii', and UDP 'CombinedTarget': whole-map blurs on the GPU against the
+    oracle's scipy restatement (f64 blur: the f32 summation order differs).  The Taylor step is pinned by the
+    reference's own vectors (taylor_coords: `_taylor` of the reference on the log maps) through a 1-tap blur."""
+    from vitpose_amd.models import keypoints_from_heatmaps as f, keypoints_from_heatmaps_device as dec
+    maps = D.synth_heatmaps(N, K, H, W, seed=70)
+    hm = torch.from_numpy(maps).to(dev)
+    c, s = gold['center'], gold['scale']
+    for kw in (dict(post_process='unbiased', kernel=11), dict(post_process='unbiased', kernel=3),
+               dict(post_process='megvii', kernel=5), dict(post_process='megvii', kernel=11)):
+        p, m = f(hm, c, s, **kw)
+        po, mo = D.keypoints_from_heatmaps(maps, c, s, **kw)
+        np.testing.assert_allclose(p, po, atol=5e-3, err_msg=str(kw))          # image pixels
+        np.testing.assert_allclose(m, mo, atol=1e-6, err_msg=str(kw))
+    # a 1-tap blur inside a zero border of 0 pixels is the identity, the rescale factor is 1: the 'unbiased' branch
+    # is then the reference's `_taylor` on log(max(map, 1e-10)) -- its own vectors
+    unit = (np.full((N, 2), [W / 2.0, H / 2.0], np.float32), np.full((N, 2), [W / 200.0, H / 200.0], np.float32))   # identity map to the image
+    p, _ = dec(hm, *unit, mode=3, kernel=1)
+    np.testing.assert_allclose(p, gold['taylor_coords'], atol=1e-4)
+    # CombinedTarget: three maps per joint (heat, x offset, y offset)
+    g = np.random.default_rng(9)
+    ct = np.zeros((N, 3 * 6, H, W), dtype=np.float32)
+    ct[:, 0::3] = maps[:, :6]
+    ct[:, 1::3] = g.uniform(-1, 1, (N, 6, H, W)).astype(np.float32)
+    ct[:, 2::3] = g.uniform(-1, 1, (N, 6, H, W)).astype(np.float32)
+    for ks in (3, 11):
+        p, m = f(torch.from_numpy(ct).to(dev), c, s, use_udp=True, target_type='CombinedTarget', kernel=ks)
+        po, mo = D.combined_target_decode(ct, c, s, kernel=ks)
+        assert p.shape == (N, 6, 2) and m.shape == (N, 6, 1)
+        np.testing.assert_allclose(p, po, atol=5e-3, err_msg=f'CombinedTarget kernel {ks}')
+        np.testing.assert_allclose(m, mo, atol=1e-6)
+
+
+def test_head_decode_every_test_cfg_on_device(dev, gold):
+    """TopdownHeatmapSimpleHead.decode (topdown_heatmap_base_head.py:40-103) with each post-processing test_cfg:
+    same keypoints as the oracle, boxes / ids / paths as the reference lays them out."""
+    from vitpose_amd.builder import build_head
+    maps = D.synth_heatmaps(N, K, H, W, seed=70)
+    c, s = gold['center'], gold['scale']
+    metas = [dict(center=c[i], scale=s[i], image_file=f'{i}.jpg', bbox_id=10 + i, bbox_score=0.5 + 0.1 * i)
+             for i in range(N)]
+    for tc, okw in ((dict(post_process='default'), dict(post_process='default')),
+                    (dict(post_process='unbiased', modulate_kernel=11), dict(post_process='unbiased', kernel=11)),
+                    (dict(post_process='megvii', modulate_kernel=5), dict(post_process='megvii', kernel=5)),
+                    (dict(post_process='default', use_udp=True, modulate_kernel=11), dict(use_udp=True, kernel=11)),
+                    (dict(unbiased_decoding=True), dict(post_process='unbiased', kernel=11))):
+        head = build_head(dict(type='TopdownHeatmapSimpleHead', in_channels=64, out_channels=K, num_deconv_layers=0,
+                               extra=dict(final_conv_kernel=1), loss_keypoint=dict(type='JointsMSELoss'),
+                               test_cfg=dict(tc)))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', DeprecationWarning)
+            for x in (maps, torch.from_numpy(maps).to(dev)):
+                res = head.decode(metas, x)
+        po, mo = D.keypoints_from_heatmaps(maps, c, s, **okw)
+        np.testing.assert_allclose(res['preds'][:, :, :2], po, atol=5e-3, err_msg=str(tc))
+        np.testing.assert_allclose(res['preds'][:, :, 2:3], mo, atol=1e-6)
+        assert res['preds'].dtype == np.float32 and res['boxes'].shape == (N, 6)
+        np.testing.assert_allclose(res['boxes'][:, 0:2], c)
+        np.testing.assert_allclose(res['boxes'][:, 2:4], s)
+        np.testing.assert_allclose(res['boxes'][:, 4], np.prod(s * 200.0, axis=1), rtol=1e-6)
+        np.testing.assert_allclose(res['boxes'][:, 5], [0.5, 0.6, 0.7, 0.8], rtol=1e-6)
+        assert res['image_paths'] == [f'{i}.jpg' for i in range(N)] and res['bbox_ids'] == [10, 11, 12, 13]
 
 
 @pytest.mark.parametrize('shift', [False, True])

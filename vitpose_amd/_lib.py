@@ -89,6 +89,7 @@ SIGNATURES = {
     'vp_generate_target': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P],
     'vp_flip_back_avg': [P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
     'vp_decode_heatmaps': [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P],
+    'vp_decode_blurred': [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_float, P],
     'vp_split_pair_f32': [P, P, c_size_t, P],
     'vp_layernorm_fwd_pair': [P, P, P, P, P, c_int, c_int, c_int, c_float, P],
     'vp_attention_split': [P, P, c_int, c_int, c_int, c_int, c_float, P],

@@ -465,49 +465,31 @@ class JointsMSELoss(nn.Module):
 # head
 # =====================================================================================
 def flip_back(output_flipped, flip_pairs, target_type='GaussianHeatmap'):
-    """core/post_processing/post_transforms.py:110-147 on host arrays (the reference consumes
-    heat maps as numpy here): swap the mirrored joints' maps, reverse the width axis."""
-    assert output_flipped.ndim == 4, 'output_flipped should be [batch_size, num_keypoints, height, width]'
-    shape_ori = output_flipped.shape
-    channels = 1
-    if target_type.lower() == 'CombinedTarget'.lower():
-        channels = 3
-        output_flipped[:, 1::3, ...] = -output_flipped[:, 1::3, ...]
-    output_flipped = output_flipped.reshape(shape_ori[0], -1, channels, shape_ori[2], shape_ori[3])
-    back = output_flipped.copy()
+    """core/post_processing/post_transforms.py:110-147 on a host array [N, K, H, W]: the maps of mirrored joints trade
+    places and the width axis is reversed ('CombinedTarget': three maps per joint, the x-offset map changes sign)."""
+    if output_flipped.ndim != 4:
+        raise AssertionError('output_flipped should be [batch_size, num_keypoints, height, width]')
+    N, C, H, W = output_flipped.shape
+    per_joint = 3 if target_type.lower() == 'combinedtarget' else 1
+    if per_joint == 3:
+        output_flipped[:, 1::3] *= -1          # in place, as the reference does (the caller's array sees it)
+    maps = output_flipped.reshape(N, C // per_joint, per_joint, H, W)
+    order = np.arange(C // per_joint)
     for left, right in flip_pairs:
-        back[:, left, ...] = output_flipped[:, right, ...]
-        back[:, right, ...] = output_flipped[:, left, ...]
-    return back.reshape(shape_ori)[..., ::-1]
+        order[left], order[right] = right, left
+    return maps[:, order].reshape(N, C, H, W)[..., ::-1]
 
 
 def transform_preds(coords, center, scale, output_size, use_udp=False):
-    """core/post_processing/post_transforms.py:150-194."""
-    assert coords.shape[1] in (2, 4, 5) and len(center) == 2 and len(scale) == 2 and len(output_size) == 2
-    scale = scale * 200.0
-    if use_udp:
-        sx, sy = scale[0] / (output_size[0] - 1.0), scale[1] / (output_size[1] - 1.0)
-    else:
-        sx, sy = scale[0] / output_size[0], scale[1] / output_size[1]
+    """core/post_processing/post_transforms.py:150-194: heat-map pixels -> image pixels of the box (center, scale * 200);
+    UDP divides by size - 1.  coords [..., >= 2] (columns beyond x, y are returned as ones, like the reference)."""
+    if coords.shape[-1] not in (2, 4, 5) or len(center) != 2 or len(scale) != 2 or len(output_size) != 2:
+        raise AssertionError('coords [.., 2|4|5], center [2], scale [2], output_size [2] expected')
+    box = np.asarray(scale, dtype=np.float64) * 200.0
+    grid = np.asarray(output_size, dtype=np.float64) - (1.0 if use_udp else 0.0)
     out = np.ones_like(coords)
-    out[:, 0] = coords[:, 0] * sx + center[0] - scale[0] * 0.5
-    out[:, 1] = coords[:, 1] * sy + center[1] - scale[1] * 0.5
+    out[..., :2] = coords[..., :2] * (box / grid) + np.asarray(center, dtype=np.float64) - 0.5 * box
     return out
-
-
-def _get_max_preds(heatmaps):
-    """core/evaluation/top_down_eval.py:63-95 on a host array."""
-    assert isinstance(heatmaps, np.ndarray), 'heatmaps should be numpy.ndarray'
-    assert heatmaps.ndim == 4, 'batch_images should be 4-ndim'
-    N, K, _, W = heatmaps.shape
-    flat = heatmaps.reshape((N, K, -1))
-    idx = np.argmax(flat, 2).reshape((N, K, 1))
-    maxvals = np.amax(flat, 2).reshape((N, K, 1))
-    preds = np.tile(idx, (1, 1, 2)).astype(np.float32)
-    preds[:, :, 0] = preds[:, :, 0] % W
-    preds[:, :, 1] = preds[:, :, 1] // W
-    preds = np.where(np.tile(maxvals, (1, 1, 2)) > 0.0, preds, -1)
-    return preds, maxvals
 
 
 def gaussian_kernel1d(ksize: int) -> np.ndarray:
@@ -525,197 +507,99 @@ def gaussian_kernel1d(ksize: int) -> np.ndarray:
     return (k / k.sum()).astype(np.float32)
 
 
-def gaussian_blur2d(img: np.ndarray, ksize: int) -> np.ndarray:
-    """cv2.GaussianBlur(img, (ksize, ksize), 0) on an f32 [H, W] array: separable, rows then columns, f32
-    intermediate, BORDER_REFLECT_101 (cv2's default border).  Returns a new array."""
-    k = gaussian_kernel1d(ksize)
-    r = ksize // 2
-    a = np.asarray(img, dtype=np.float32)
-    for axis in (1, 0):
-        pad = [(0, 0), (0, 0)]
-        pad[axis] = (r, r)
-        ap = np.pad(a, pad, mode='reflect')
-        out = np.zeros_like(a)
-        n = a.shape[axis]
-        for t in range(ksize):
-            sl = [slice(None), slice(None)]
-            sl[axis] = slice(t, t + n)
-            out += k[t] * ap[tuple(sl)]
-        a = out
-    return a
-
-
-def _gaussian_blur(heatmaps, kernel=11):
-    """top_down_eval.py:399-438: blur inside a zero border, then restore each map's maximum."""
-    assert kernel % 2 == 1
-    border = (kernel - 1) // 2
-    N, K, H, W = heatmaps.shape
-    for i in range(N):
-        for j in range(K):
-            origin_max = np.max(heatmaps[i, j])
-            dr = np.zeros((H + 2 * border, W + 2 * border), dtype=np.float32)
-            dr[border:-border, border:-border] = heatmaps[i, j].copy()
-            dr = gaussian_blur2d(dr, kernel)
-            heatmaps[i, j] = dr[border:-border, border:-border].copy()
-            heatmaps[i, j] *= origin_max / np.max(heatmaps[i, j])
-    return heatmaps
-
-
-def _taylor(heatmap, coord):
-    """top_down_eval.py:298-332 (DARK: second-order Taylor step on the log heat map)."""
-    H, W = heatmap.shape[:2]
-    px, py = int(coord[0]), int(coord[1])
-    if 1 < px < W - 2 and 1 < py < H - 2:
-        dx = 0.5 * (heatmap[py][px + 1] - heatmap[py][px - 1])
-        dy = 0.5 * (heatmap[py + 1][px] - heatmap[py - 1][px])
-        dxx = 0.25 * (heatmap[py][px + 2] - 2 * heatmap[py][px] + heatmap[py][px - 2])
-        dxy = 0.25 * (heatmap[py + 1][px + 1] - heatmap[py - 1][px + 1] - heatmap[py + 1][px - 1]
-                      + heatmap[py - 1][px - 1])
-        dyy = 0.25 * (heatmap[py + 2][px] - 2 * heatmap[py][px] + heatmap[py - 2][px])
-        if dxx * dyy - dxy ** 2 != 0:
-            hinv = np.linalg.inv(np.array([[dxx, dxy], [dxy, dyy]]))
-            coord += np.squeeze(np.array((-hinv @ np.array([[dx], [dy]])).T), axis=0)
-    return coord
-
-
-def post_dark_udp(coords, batch_heatmaps, kernel=3):
-    """top_down_eval.py:335-396: blur, clip to [0.001, 50], log, Newton step with the 3 x 3 stencil on
-    the edge-padded map.  Host version; `decode_udp_device` is the same arithmetic on the GPU."""
-    B, K, H, W = batch_heatmaps.shape
-    N = coords.shape[0]
-    assert B == 1 or B == N
-    for heatmaps in batch_heatmaps:
-        for heatmap in heatmaps:
-            heatmap[...] = gaussian_blur2d(heatmap, kernel)
-    np.clip(batch_heatmaps, 0.001, 50, batch_heatmaps)
-    np.log(batch_heatmaps, batch_heatmaps)
-    pad = np.pad(batch_heatmaps, ((0, 0), (0, 0), (1, 1), (1, 1)), mode='edge').flatten()
-    index = coords[..., 0] + 1 + (coords[..., 1] + 1) * (W + 2)
-    index += (W + 2) * (H + 2) * np.arange(0, B * K).reshape(-1, K)
-    index = index.astype(int).reshape(-1, 1)
-    i_, ix1, iy1 = pad[index], pad[index + 1], pad[index + W + 2]
-    ix1y1, ix1_y1_ = pad[index + W + 3], pad[index - W - 3]
-    ix1_, iy1_ = pad[index - 1], pad[index - 2 - W]
-    dx, dy = 0.5 * (ix1 - ix1_), 0.5 * (iy1 - iy1_)
-    derivative = np.concatenate([dx, dy], axis=1).reshape(N, K, 2, 1)
-    dxx, dyy = ix1 - 2 * i_ + ix1_, iy1 - 2 * i_ + iy1_
-    dxy = 0.5 * (ix1y1 - ix1 - iy1 + i_ + i_ - ix1_ - iy1_ + ix1_y1_)
-    hessian = np.concatenate([dxx, dxy, dxy, dyy], axis=1).reshape(N, K, 2, 2)
-    hessian = np.linalg.inv(hessian + np.finfo(np.float32).eps * np.eye(2))
-    coords -= np.einsum('ijmn,ijnk->ijmk', hessian, derivative).squeeze(-1)
-    return coords
-
-
-def keypoints_from_heatmaps(heatmaps, center, scale, unbiased=False, post_process='default', kernel=11,
-                            valid_radius_factor=0.0546875, use_udp=False, target_type='GaussianHeatmap'):
-    """core/evaluation/top_down_eval.py:474-622, every branch: post_process None / 'default' / 'unbiased'
-    (DARK) / 'megvii', and UDP with 'GaussianHeatmap' (DARK-UDP) or 'CombinedTarget' targets.  The
-    reference blurs with cv2.GaussianBlur; `gaussian_blur2d` restates that filter."""
-    heatmaps = heatmaps.copy()
-    if unbiased:
-        assert post_process not in [False, None, 'megvii']
-    if post_process in ['megvii', 'unbiased']:
-        assert kernel > 0
-    if use_udp:
-        assert not post_process == 'megvii'
-    if post_process is False:
-        warnings.warn('post_process=False is deprecated, please use post_process=None instead', DeprecationWarning)
-        post_process = None
-    elif post_process is True:
-        if unbiased is True:
-            warnings.warn("post_process=True, unbiased=True is deprecated, please use post_process='unbiased' instead",
-                          DeprecationWarning)
-            post_process = 'unbiased'
-        else:
-            warnings.warn("post_process=True, unbiased=False is deprecated, please use post_process='default' instead",
-                          DeprecationWarning)
-            post_process = 'default'
-    elif post_process == 'default':
-        if unbiased is True:
-            warnings.warn("unbiased=True is deprecated, please use post_process='unbiased' instead",
-                          DeprecationWarning)
-            post_process = 'unbiased'
-    if post_process == 'megvii':
-        heatmaps = _gaussian_blur(heatmaps, kernel=kernel)
-    N, K, H, W = heatmaps.shape
-    if use_udp:
-        if target_type.lower() == 'GaussianHeatMap'.lower():
-            preds, maxvals = _get_max_preds(heatmaps)
-            preds = post_dark_udp(preds, heatmaps, kernel=kernel)
-        elif target_type.lower() == 'CombinedTarget'.lower():
-            for person_heatmaps in heatmaps:
-                for i, heatmap in enumerate(person_heatmaps):
-                    kt = 2 * kernel + 1 if i % 3 == 0 else kernel
-                    heatmap[...] = gaussian_blur2d(heatmap, kt)
-            valid_radius = valid_radius_factor * H
-            offset_x = heatmaps[:, 1::3, :].flatten() * valid_radius
-            offset_y = heatmaps[:, 2::3, :].flatten() * valid_radius
-            heatmaps = heatmaps[:, ::3, :]
-            preds, maxvals = _get_max_preds(heatmaps)
-            index = preds[..., 0] + preds[..., 1] * W
-            index += W * H * np.arange(0, N * K / 3)
-            index = index.astype(int).reshape(N, K // 3, 1)
-            preds += np.concatenate((offset_x[index], offset_y[index]), axis=2)
-        else:
-            raise ValueError("target_type should be either 'GaussianHeatmap' or 'CombinedTarget'")
-    else:
-        preds, maxvals = _get_max_preds(heatmaps)
-        if post_process == 'unbiased':
-            heatmaps = np.log(np.maximum(_gaussian_blur(heatmaps, kernel), 1e-10))
-            for n in range(N):
-                for k in range(K):
-                    preds[n][k] = _taylor(heatmaps[n][k], preds[n][k])
-        elif post_process is not None:
-            for n in range(N):
-                for k in range(K):
-                    hm = heatmaps[n][k]
-                    px, py = int(preds[n][k][0]), int(preds[n][k][1])
-                    if 1 < px < W - 1 and 1 < py < H - 1:
-                        diff = np.array([hm[py][px + 1] - hm[py][px - 1], hm[py + 1][px] - hm[py - 1][px]])
-                        preds[n][k] += np.sign(diff) * .25
-                        if post_process == 'megvii':
-                            preds[n][k] += 0.5
-    for i in range(N):
-        preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H], use_udp=use_udp)
-    if post_process == 'megvii':
-        maxvals = maxvals / 255.0 + 0.5
-    return preds, maxvals
-
-
 def _stream_ptr():
     import ctypes
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def device_decode_mode(unbiased=False, post_process='default', use_udp=False, target_type='GaussianHeatmap'):
-    """Which vp_decode_heatmaps mode evaluates these keypoints_from_heatmaps settings (None: host only)."""
-    if unbiased or post_process in ('megvii', 'unbiased', True, False):
-        return None
+# vp_decode_heatmaps / vp_decode_blurred modes
+_MODE_NONE, _MODE_SHIFT, _MODE_DARK_UDP, _MODE_DARK, _MODE_MEGVII, _MODE_COMBINED = 0, 1, 2, 3, 4, 5
+
+
+def _post_process_mode(unbiased, post_process, kernel, use_udp, target_type):
+    """The argument rules of keypoints_from_heatmaps (top_down_eval.py:517-560) -> (device mode, normalised
+    post_process).  Legacy spellings (booleans, unbiased=True) are accepted with a DeprecationWarning."""
+    if unbiased and post_process in (False, None, 'megvii'):
+        raise AssertionError('unbiased decoding needs post_process "default" / "unbiased"')
+    if post_process in ('megvii', 'unbiased') and not kernel > 0:
+        raise AssertionError('post_process "megvii" / "unbiased" blur the maps: kernel must be > 0')
+    if use_udp and post_process == 'megvii':
+        raise AssertionError('UDP decoding has no "megvii" variant')
+    legacy = None
+    if post_process is False:
+        legacy, post_process = 'post_process=False', None
+    elif post_process is True:
+        legacy = f'post_process=True, unbiased={bool(unbiased)}'
+        post_process = 'unbiased' if unbiased is True else 'default'
+    elif post_process == 'default' and unbiased is True:
+        legacy, post_process = 'unbiased=True', 'unbiased'
+    if legacy is not None:
+        warnings.warn(f'{legacy} is a deprecated spelling of post_process={post_process!r}', DeprecationWarning)
     if use_udp:
-        return 2 if target_type.lower() == 'gaussianheatmap' else None
-    return 1 if post_process == 'default' else (0 if post_process is None else None)
+        tt = target_type.lower()
+        if tt == 'gaussianheatmap':
+            return _MODE_DARK_UDP, post_process
+        if tt == 'combinedtarget':
+            return _MODE_COMBINED, post_process
+        raise ValueError("target_type should be either 'GaussianHeatmap' or 'CombinedTarget'")
+    return {None: _MODE_NONE, 'default': _MODE_SHIFT, 'unbiased': _MODE_DARK, 'megvii': _MODE_MEGVII}[post_process], post_process
 
 
-def keypoints_from_heatmaps_device(heatmaps: torch.Tensor, center, scale, mode: int, kernel=11, use_udp=False):
-    """keypoints_from_heatmaps (top_down_eval.py:474-622) with the per-map work (arg-max, blur, log,
-    Newton step) in one HIP kernel: heat maps stay on the GPU, [N, K, 3] numbers come back."""
+def device_decode_mode(unbiased=False, post_process='default', use_udp=False, target_type='GaussianHeatmap', kernel=11):
+    """Which device mode evaluates these keypoints_from_heatmaps settings (every combination the reference
+    accepts has one)."""
+    return _post_process_mode(unbiased, post_process, kernel, use_udp, target_type)[0]
+
+
+def keypoints_from_heatmaps_device(heatmaps: torch.Tensor, center, scale, mode: int, kernel=11, use_udp=False,
+                                   valid_radius_factor=0.0546875):
+    """The per-map work of keypoints_from_heatmaps (arg-max, blur, log, Newton / Taylor step, offsets) in one HIP
+    launch -- heat maps stay on the GPU, [N, K, 3] numbers come back -- then the map to image coordinates."""
     import ctypes
-    _need_hip(heatmaps, 'keypoints_from_heatmaps_device')
-    N, K, H, W = heatmaps.shape
+    _need_hip(heatmaps, 'keypoints_from_heatmaps')
+    N, C, H, W = heatmaps.shape
+    K = C // 3 if mode == _MODE_COMBINED else C
     hm = heatmaps.detach().contiguous().float()
-    out = torch.empty(N * K, 3, dtype=torch.float32, device=hm.device)
-    preds_d, max_d = out[:, :2].contiguous(), out[:, 2].contiguous()
-    taps = gaussian_kernel1d(kernel) if mode == 2 else np.zeros(1, np.float32)
-    taps_c = (ctypes.c_float * len(taps))(*taps.tolist())
-    rc = _lib.lib().vp_decode_heatmaps(hm.data_ptr(), preds_d.data_ptr(), max_d.data_ptr(), N * K, H, W, mode,
-                                       taps_c, len(taps), _stream_ptr())
+    preds_d = torch.empty(N * K, 2, dtype=torch.float32, device=hm.device)
+    max_d = torch.empty(N * K, dtype=torch.float32, device=hm.device)
+    L = _lib.lib()
+
+    def carr(a):
+        return (ctypes.c_float * len(a))(*np.asarray(a, dtype=np.float32).tolist())
+    if mode <= _MODE_DARK_UDP:
+        taps = gaussian_kernel1d(kernel) if mode == _MODE_DARK_UDP else np.zeros(1, np.float32)
+        rc = L.vp_decode_heatmaps(hm.data_ptr(), preds_d.data_ptr(), max_d.data_ptr(), N * K, H, W, mode,
+                                  carr(taps), len(taps), _stream_ptr())
+    else:
+        taps = gaussian_kernel1d(kernel)
+        taps2 = gaussian_kernel1d(2 * kernel + 1) if mode == _MODE_COMBINED else taps
+        rc = L.vp_decode_blurred(hm.data_ptr(), preds_d.data_ptr(), max_d.data_ptr(), N * K, H, W, mode,
+                                 carr(taps), len(taps), carr(taps2), len(taps2), float(valid_radius_factor * H),
+                                 _stream_ptr())
     if rc != 0:
-        raise RuntimeError(f'vp_decode_heatmaps failed with status {rc}')
-    preds = preds_d.cpu().numpy().reshape(N, K, 2)
+        raise RuntimeError(f'heat-map decode failed with status {rc} (mode {mode}, kernel {kernel}, maps {H}x{W})')
+    coords = preds_d.cpu().numpy().reshape(N, K, 2)
     maxvals = max_d.cpu().numpy().reshape(N, K, 1)
-    for i in range(N):
-        preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H], use_udp=use_udp)
+    # heat-map pixels -> image pixels, every person at once (transform_preds per person in the reference)
+    box = np.asarray(scale, dtype=np.float64).reshape(N, 1, 2) * 200.0
+    grid = np.array([W, H], dtype=np.float64) - (1.0 if use_udp else 0.0)
+    preds = (coords * (box / grid) + np.asarray(center, dtype=np.float64).reshape(N, 1, 2) - 0.5 * box).astype(np.float32)
     return preds, maxvals
+
+
+def keypoints_from_heatmaps(heatmaps, center, scale, unbiased=False, post_process='default', kernel=11,
+                            valid_radius_factor=0.0546875, use_udp=False, target_type='GaussianHeatmap'):
+    """core/evaluation/top_down_eval.py:474-622, every branch (post_process None / 'default' / 'unbiased' /
+    'megvii', UDP with 'GaussianHeatmap' or 'CombinedTarget' targets), evaluated on the GPU: `heatmaps` may be
+    a device tensor (stays there) or a host array (uploaded to the current HIP device; the array is not
+    modified).  Returns (preds [N, K, 2] in image pixels, maxvals [N, K, 1]) as numpy arrays."""
+    mode, _ = _post_process_mode(unbiased, post_process, kernel, use_udp, target_type)
+    if not torch.is_tensor(heatmaps):
+        if not torch.cuda.is_available():
+            raise RuntimeError('keypoints_from_heatmaps runs on an MI355X (HIP device) only; there is no CPU path')
+        heatmaps = torch.from_numpy(np.ascontiguousarray(heatmaps, dtype=np.float32)).cuda()
+    return keypoints_from_heatmaps_device(heatmaps, center, scale, mode, kernel=kernel, use_udp=use_udp,
+                                          valid_radius_factor=valid_radius_factor)
 
 
 def flip_back_avg_device(heat: torch.Tensor, heat_flipped: torch.Tensor, flip_pairs, shift: bool) -> torch.Tensor:
@@ -924,45 +808,25 @@ class TopdownHeatmapSimpleHead(_FlatBound):
         return output_heatmap
 
     def decode(self, img_metas, output, **kwargs):
-        """topdown_heatmap_base_head.py:40-103."""
-        batch_size = len(img_metas)
-        bbox_ids = [] if 'bbox_id' in img_metas[0] else None
-        c = np.zeros((batch_size, 2), dtype=np.float32)
-        s = np.zeros((batch_size, 2), dtype=np.float32)
-        image_paths = []
-        score = np.ones(batch_size)
-        for i in range(batch_size):
-            c[i, :] = img_metas[i]['center']
-            s[i, :] = img_metas[i]['scale']
-            image_paths.append(img_metas[i]['image_file'])
-            if 'bbox_score' in img_metas[i]:
-                score[i] = np.array(img_metas[i]['bbox_score']).reshape(-1)[0]
-            if bbox_ids is not None:
-                bbox_ids.append(img_metas[i]['bbox_id'])
-        kw = dict(unbiased=self.test_cfg.get('unbiased_decoding', False),
-                  post_process=self.test_cfg.get('post_process', 'default'),
-                  use_udp=self.test_cfg.get('use_udp', False),
-                  target_type=self.test_cfg.get('target_type', 'GaussianHeatmap'))
-        kernel = self.test_cfg.get('modulate_kernel', 11)
-        mode = device_decode_mode(**kw) if torch.is_tensor(output) and output.is_cuda else None
-        if mode is not None:
-            # heat maps still on the GPU: decode there, only [N, K, 3] numbers cross to the host
-            preds, maxvals = keypoints_from_heatmaps_device(output, c, s, mode, kernel=kernel, use_udp=kw['use_udp'])
-        else:
-            if torch.is_tensor(output):
-                output = output.detach().cpu().numpy()
-            preds, maxvals = keypoints_from_heatmaps(
-                output, c, s, kernel=kernel,
-                valid_radius_factor=self.test_cfg.get('valid_radius_factor', 0.0546875), **kw)
-        all_preds = np.zeros((batch_size, preds.shape[1], 3), dtype=np.float32)
-        all_boxes = np.zeros((batch_size, 6), dtype=np.float32)
-        all_preds[:, :, 0:2] = preds[:, :, 0:2]
-        all_preds[:, :, 2:3] = maxvals
-        all_boxes[:, 0:2] = c[:, 0:2]
-        all_boxes[:, 2:4] = s[:, 0:2]
-        all_boxes[:, 4] = np.prod(s * 200.0, axis=1)
-        all_boxes[:, 5] = score
-        return dict(preds=all_preds, boxes=all_boxes, image_paths=image_paths, bbox_ids=bbox_ids)
+        """topdown_heatmap_base_head.py:40-103: heat maps -> `preds` [N, K, 3] (x, y, score in image pixels),
+        `boxes` [N, 6] (center, scale, area, score), `image_paths`, `bbox_ids`.  The heat maps are decoded on
+        the GPU whatever test_cfg selects (a host array is uploaded first)."""
+        n = len(img_metas)
+        center = np.array([np.asarray(m['center'], dtype=np.float32).reshape(2) for m in img_metas], dtype=np.float32)
+        scale = np.array([np.asarray(m['scale'], dtype=np.float32).reshape(2) for m in img_metas], dtype=np.float32)
+        score = np.array([np.asarray(m['bbox_score']).reshape(-1)[0] if 'bbox_score' in m else 1.0 for m in img_metas],
+                         dtype=np.float64)
+        cfg = self.test_cfg
+        preds, maxvals = keypoints_from_heatmaps(
+            output, center, scale, unbiased=cfg.get('unbiased_decoding', False),
+            post_process=cfg.get('post_process', 'default'), kernel=cfg.get('modulate_kernel', 11),
+            valid_radius_factor=cfg.get('valid_radius_factor', 0.0546875), use_udp=cfg.get('use_udp', False),
+            target_type=cfg.get('target_type', 'GaussianHeatmap'))
+        boxes = np.concatenate([center, scale, np.prod(scale * 200.0, axis=1, keepdims=True), score[:, None]],
+                               axis=1).astype(np.float32)
+        return dict(preds=np.concatenate([preds[:, :, :2], maxvals], axis=2).astype(np.float32), boxes=boxes,
+                    image_paths=[m['image_file'] for m in img_metas],
+                    bbox_ids=[m['bbox_id'] for m in img_metas] if 'bbox_id' in img_metas[0] else None)
 
     def _transform_inputs(self, inputs):
         """topdown_heatmap_simple_head.py:269-304 (the ReLU + resize of a tensor input happens inside
