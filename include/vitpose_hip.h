@@ -143,7 +143,8 @@ int vp_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, con
  * backward passes whose parameter gradients nobody reads before the optimizer or the gradient exchange).
  * `table_dev` lives in device memory; NULL targets of an entry are skipped. */
 typedef struct vp_ln_partial {
-    const float* partial; float* dgamma; float* dbeta; float* dcolsum; int blocks; int reserved;
+    const float* partial; float* dgamma; float* dbeta; float* dcolsum; int blocks;
+    int overwrite;   /* 0: the sums are added to the targets; 1: they replace what the targets hold */
 } vp_ln_partial;   /* 40 bytes */
 int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats);
 int vp_layernorm_bwd_finalize(const vp_ln_partial* table_dev, int count, int E, vp_stream_t stream);
@@ -396,6 +397,24 @@ int vp_sumsq_f32(const float* x, size_t n, float* out, vp_stream_t stream);
  * scratch, then one workgroup adds them): bit-identical on every data-parallel replica that holds the same gradients,
  * which the atomics of vp_sumsq_f32 do not guarantee. */
 int vp_sumsq_f32_det(const float* x, size_t n, float* out, float* partials, int npartials, vp_stream_t stream);
+/* sum x^2 over the chunks of the optimizer's table only ({start, length} in elements, lengths multiples of 4): the
+ * norm torch's clip_grad_norm_ takes over the parameters that have a gradient -- frozen parameters (no chunk) stay out
+ * (mmcv OptimizerHook.clip_grads filters on requires_grad).  Fixed summation order; *out is ASSIGNED. */
+int vp_sumsq_chunks_det(const float* x, const long* chunk_start, const int* chunk_len, int nchunks, float* out,
+                        float* partials, int npartials, vp_stream_t stream);
+/* DropPath.forward (vit.py:48-59 -> timm drop_path): dp[i][...] = floor(keep_i + U[0,1)) / keep_i per sample,
+ * keep_i = 1 - rates[i] (rates on the device; rate 0 -> exactly 1: Block 0 and Blocks in eval mode), `per_block`
+ * values per Block.  U comes from Philox-4x32-10 keyed by (seed, counter): one counter value per training step. */
+int vp_drop_path_scales(float* dp, const float* rates, int depth, int per_block, unsigned long long seed,
+                        unsigned long long counter, vp_stream_t stream);
+/* x (bf16, n % 8 == 0) *= *scale_dev: seeds the backward pass with the incoming dL/dloss (autograd hands
+ * TopDown.forward_train's loss a device scalar). */
+int vp_scale_bf16(void* x, size_t n, const float* scale_dev, vp_stream_t stream);
+/* hipMemsetAsync(p, 0, bytes) on `stream` (accumulating reductions start from zero). */
+int vp_zero(void* p, size_t bytes, vp_stream_t stream);
+/* Gradient of pos_embed [1][1 + T][E] from the gradient dx [B][T][E] of the embedded tokens (vit.py:320:
+ * x + pos_embed[:, 1:] + pos_embed[:, :1]): rows 1 .. T = sum over images, row 0 = sum of those rows.  Overwrites. */
+int vp_pos_embed_grad(const float* dx, float* gpos, int B, int T, int E, vp_stream_t stream);
 int vp_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, const long* chunk_start,
                   const int* chunk_len, const float* chunk_lr_scale, const float* chunk_wd, int nchunks,
                   float lr, float beta1, float beta2, float eps, int step, const float* gnorm_sq,

@@ -1,0 +1,226 @@
+"""Training-state behaviour of the fused TopDown on the GPU that the host-only tests cannot see:
+  * every element of the flat gradient buffer is stored by the backward plan (there is no gradient memset);
+  * frozen parameters (ViT frozen_stages / freeze_attn / freeze_ffn, vit.py:249-284) stay out of the clip norm and
+    are not updated; frozen Blocks sample no DropPath; the rest steps like torch clip_grad_norm_ + AdamW;
+  * the optimizer state survives save_checkpoint / load_state_dict (mmcv_custom/checkpoint.py:490-552);
+  * a 14 x 14 MAE-shaped checkpoint loads into a model that already lives on the device
+    (mmcv_custom/checkpoint.py:360-394) and the forward pass uses the adapted weights;
+  * the DropPath sampling kernel draws what timm's drop_path draws (vit.py:48-59)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitpose_oracle as O
+
+pytestmark = pytest.mark.gpu
+LOSS = dict(type='JointsMSELoss', use_target_weight=True)
+TOY = dict(img_size=(256, 192), patch_size=16, in_chans=3, embed_dim=64, depth=3, num_heads=2,
+           mlp_ratio=4, qkv_bias=True, ratio=1, last_norm=True, drop_path_rate=0.0)
+OPT = dict(type='AdamW', lr=1e-3, betas=(0.9, 0.999), weight_decay=0.1, constructor='LayerDecayOptimizerConstructor',
+           paramwise_cfg=dict(num_layers=3, layer_decay_rate=0.75))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def build(dev, head='classic', **backbone_kw):
+    from vitpose_amd.builder import build_posenet
+    ohc = O.classic_head_cfg(64) if head == 'classic' else O.simple_head_cfg(64)
+    hc = dict(ohc, type='TopdownHeatmapSimpleHead', loss_keypoint=dict(LOSS))
+    m = build_posenet(dict(type='TopDown', backbone=dict(TOY, type='ViT', **backbone_kw), keypoint_head=hc,
+                           train_cfg=dict(skip_accuracy=True), test_cfg=dict(flip_test=False)))
+    bb, hd = O.synth_vit_weights(TOY, seed=1), O.synth_head_weights(ohc, seed=2)
+    sd = {'backbone.' + k: v for k, v in bb.items()}
+    sd.update({'keypoint_head.' + k: v for k, v in hd.items()})
+    m.load_state_dict(sd, strict=False)
+    return m.to(dev), ohc
+
+
+@pytest.mark.parametrize('head', ['classic', 'simple'])
+def test_backward_stores_every_gradient_element(dev, head):
+    """No gradient memset: poison every parameter's slice of the flat gradient buffer, run one forward + backward, and
+    every gradient must come back finite (stored, not accumulated) and equal to the pass from a clean buffer."""
+    m, _ = build(dev, head)
+    m.train()
+    eng = m._engine
+    img, target, tw = (t.to(dev) for t in O.synth_batch(2, seed=3))
+    eng.forward_backward(img, target, tw, drop_path=False)
+    clean = eng.store.grad.clone()
+    for n in eng.store.names:
+        eng.store.gview(n).fill_(float('nan'))
+    eng.forward_backward(img, target, tw, drop_path=False)
+    torch.cuda.synchronize()
+    for n in eng.store.names:
+        g = eng.store.gview(n)
+        assert torch.isfinite(g).all(), n
+        # and it is the same gradient as from a clean buffer (float atomics in a few reductions: not bit-equal)
+        c = clean[eng.store.offsets[n]:eng.store.offsets[n] + g.numel()].view_as(g)
+        assert ((g - c).norm() / c.norm().clamp_min(1e-20)).item() < 2e-2, n
+
+
+def test_alignment_gaps_stay_zero_without_poison(dev):
+    m, _ = build(dev)
+    m.train()
+    eng = m._engine
+    img, target, tw = (t.to(dev) for t in O.synth_batch(2, seed=3))
+    eng.forward_backward(img, target, tw, drop_path=False)
+    torch.cuda.synchronize()
+    covered = torch.zeros(eng.store.numel, dtype=torch.bool, device=dev)
+    for n in eng.store.names:
+        o = eng.store.offsets[n]
+        covered[o:o + eng.store.gview(n).numel()] = True
+    assert float(eng.store.grad[~covered].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('kw', [dict(frozen_stages=1), dict(freeze_attn=True), dict(freeze_ffn=True)])
+def test_frozen_parameters_clip_norm_and_update(dev, kw):
+    m, ohc = build(dev, drop_path_rate=0.3, **kw)
+    m.train()
+    frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
+    assert frozen
+    opt = m.build_optimizer(dict(OPT), grad_clip=dict(max_norm=0.05, norm_type=2))
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    img, target, tw = (t.to(dev) for t in O.synth_batch(2, seed=3))
+    out = m.forward_train(img, target, tw, None)
+    out['heatmap_loss'].backward()
+    eng = m._engine
+    # frozen Blocks are in eval mode (vit.py:249-284): their DropPath is the identity
+    dp = eng._train_plan(2)[1]['dp']
+    for i, blk in enumerate(m.backbone.blocks):
+        if not blk.training:
+            assert float((dp[i] - 1).abs().max()) == 0.0, i
+    grads = {n: eng.store.gview(n).detach().clone() for n in eng.store.names}
+    opt.step()
+    torch.cuda.synchronize()
+    # the clip factor comes from the norm over the parameters the optimizer owns
+    want = torch.sqrt(sum((g.double() ** 2).sum() for n, g in grads.items() if n not in frozen))
+    allp = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
+    got = eng.optimizer.gnorm_sq.double().sqrt().item()
+    assert abs(got - want.item()) < 1e-5 * want.item()
+    assert allp.item() > want.item() * (1 + 1e-4)        # the frozen gradients are non-zero: the old norm was larger
+    assert want.item() > 0.05                            # the clip is active
+    for n, p in m.named_parameters():
+        if n in frozen:
+            assert torch.equal(p.detach(), before[n]), n
+        elif float(grads[n].abs().max()) > 0:        # (a branch DropPath dropped for every image has no gradient)
+            assert not torch.equal(p.detach(), before[n]), n
+    # the update of the trainable tensors = torch's clip_grad_norm_ + AdamW on the same gradients
+    from vitpose_amd.optim import layer_decay_param_groups
+    named = [(n, tuple(p.shape)) for n, p in m.named_parameters()]
+    groups = layer_decay_param_groups(named, 3, 0.75, 1e-3, 0.1)
+    tp = {n: before[n].clone().requires_grad_() for n in before if n not in frozen}
+    for n, p in tp.items():
+        p.grad = grads[n].clone()
+    topt = torch.optim.AdamW([dict(params=[p], lr=groups[n]['lr'], weight_decay=groups[n]['weight_decay'])
+                              for n, p in tp.items()], lr=1e-3)
+    torch.nn.utils.clip_grad_norm_(list(tp.values()), 0.05)
+    topt.step()
+    for n, p in tp.items():
+        torch.testing.assert_close(dict(m.named_parameters())[n].detach(), p.detach(), rtol=1e-5, atol=1e-7, msg=n)
+
+
+def test_optimizer_state_checkpoint_round_trip(dev, tmp_path):
+    from vitpose_amd.checkpoint import save_checkpoint
+    batch = [t.to(dev) for t in O.synth_batch(2, seed=3)]
+
+    def step(model, opt):
+        model.forward_train(*batch, None)['heatmap_loss'].backward()
+        opt.step()
+        opt.zero_grad()
+    m, _ = build(dev)
+    m.train()
+    opt = m.build_optimizer(dict(OPT), grad_clip=dict(max_norm=1.0, norm_type=2))
+    for _ in range(3):
+        step(m, opt)
+    f = str(tmp_path / 'ck.pth')
+    save_checkpoint(m, f, optimizer=opt, meta=dict(iter=3))
+    with pytest.raises(TypeError):
+        save_checkpoint(m, str(tmp_path / 'bad.pth'), optimizer=object())
+    ck = torch.load(f, weights_only=True)
+    assert set(ck) == {'meta', 'state_dict', 'optimizer'} and ck['optimizer']['step'] == 3
+    assert set(ck['optimizer']['state']) == {n for n, _ in m.named_parameters()}
+
+    def resume(with_state):
+        m2, _ = build(dev)
+        m2.load_state_dict(ck['state_dict'])
+        m2.train()
+        o2 = m2.build_optimizer(dict(OPT), grad_clip=dict(max_norm=1.0, norm_type=2))
+        if with_state:
+            o2.load_state_dict(ck['optimizer'])
+            assert m2._engine.optimizer.step_count == 3
+        step(m2, o2)
+        return m2
+    step(m, opt)                                    # the run that never stopped
+    resumed, fresh = resume(True), resume(False)
+    n = 'backbone.blocks.1.mlp.fc1.weight'
+    w = dict(m.named_parameters())[n].detach()
+    d_res = (dict(resumed.named_parameters())[n].detach() - w).abs().max().item()
+    d_fresh = (dict(fresh.named_parameters())[n].detach() - w).abs().max().item()
+    # resumed moments: the fourth update repeats (up to the float atomics of the reductions); a fresh optimizer
+    # restarts the bias correction and takes a first-step-sized (lr) update instead
+    assert d_res < 2e-5 and d_fresh > 20 * max(d_res, 1e-7), (d_res, d_fresh)
+    with pytest.raises(KeyError):
+        bad = dict(ck['optimizer'], state={k: v for k, v in list(ck['optimizer']['state'].items())[1:]})
+        resumed._engine.optimizer.load_state_dict(bad)
+
+
+def test_mae_checkpoint_loads_into_a_model_on_the_device(dev, tmp_path):
+    """A 14 x 14 patch kernel and a 14 x 14 (+ cls) position table enter a ViT that already lives on the GPU: the flat
+    store (f32 master + bf16 mirror + derived position sums) follows, and the forward pass is the oracle's on the
+    adapted weights."""
+    from vitpose_amd.checkpoint import adapt_backbone_state_dict, load_checkpoint
+    m, ohc = build(dev)
+    m.eval()
+    bb = O.synth_vit_weights(TOY, seed=7)
+    g = torch.Generator().manual_seed(0)
+    mae = dict(bb)
+    mae['patch_embed.proj.weight'] = torch.randn(64, 3, 14, 14, generator=g) * 0.05
+    mae['pos_embed'] = torch.randn(1, 14 * 14 + 1, 64, generator=g) * 0.5
+    f = str(tmp_path / 'mae.pth')
+    torch.save({'model': {'module.' + k: v for k, v in mae.items()}}, f)
+    load_checkpoint(m.backbone, f, strict=True)
+    adapted = adapt_backbone_state_dict(m.backbone, mae, 'pad')
+    assert adapted['patch_embed.proj.weight'].shape == (64, 3, 16, 16) and adapted['pos_embed'].shape == (1, 193, 64)
+    assert torch.equal(m.backbone.pos_embed.detach().cpu(), adapted['pos_embed'])
+    assert m.backbone.pos_embed.data_ptr() == m._engine.store.view('backbone.pos_embed').data_ptr()
+    img, _, _ = O.synth_batch(2, seed=5)
+    hd = {k[len('keypoint_head.'):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith('keypoint_head.')}
+    with torch.no_grad():
+        ref = O.head_forward(hd, O.vit_forward({k: v for k, v in adapted.items()}, img, TOY), ohc, training=False)
+        got = m.forward_dummy(img.to(dev)).cpu()
+    assert ((got - ref).norm() / ref.norm()).item() < 9e-3
+    m2, _ = build(dev)                                        # the weights it had before differ visibly
+    with torch.no_grad():
+        assert ((m2.eval().forward_dummy(img.to(dev)).cpu() - ref).norm() / ref.norm()).item() > 0.1
+
+
+def test_drop_path_kernel_statistics(dev):
+    """floor(keep + U) / keep per (Block, site, sample): values are 0 or 1 / keep, the kept fraction is keep, rate 0
+    gives exactly 1, successive steps differ, inactive (eval-mode) Blocks give 1."""
+    from vitpose_amd.engine import ParamStore, VitRunner, vit_param_shapes
+    cfg = dict(TOY, depth=4, drop_path_rate=0.6)
+    vr = VitRunner(cfg, ParamStore(vit_param_shapes(cfg), dev))
+    B = 4096
+    dp = torch.empty(4, 2, B, device=dev)
+    vr.sample_drop_path(dp)
+    first = dp.clone()
+    rates = [0.0, 0.2, 0.4, 0.6]
+    assert float((dp[0] - 1).abs().max()) == 0.0
+    for i in (1, 2, 3):
+        keep = 1 - rates[i]
+        vals = torch.unique(dp[i])
+        assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / keep) < 1e-6
+        frac = (dp[i] > 0).float().mean().item()
+        assert abs(frac - keep) < 4 * np.sqrt(keep * (1 - keep) / (2 * B)), (i, frac)
+        assert abs(dp[i].mean().item() - 1.0) < 0.05               # unbiased: E[scale] = 1
+    vr.sample_drop_path(dp)
+    assert not torch.equal(dp, first)
+    vr.sample_drop_path(dp, active=[True, False, True, False])
+    assert float((dp[1] - 1).abs().max()) == 0.0 and float((dp[3] - 1).abs().max()) == 0.0
+    assert (dp[2] == 0).any()

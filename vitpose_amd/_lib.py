@@ -50,7 +50,7 @@ class GroupEntry(Structure):
 
 class LnPartial(Structure):
     _fields_ = [('partial', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p), ('dcolsum', c_void_p),
-                ('blocks', c_int), ('reserved', c_int)]
+                ('blocks', c_int), ('overwrite', c_int)]
 
 
 SIGNATURES = {
@@ -100,6 +100,11 @@ SIGNATURES = {
     'vp_argmax_rows': [P, c_int, c_int, P, P, P],
     'vp_sumsq_f32': [P, c_size_t, P, P],
     'vp_sumsq_f32_det': [P, c_size_t, P, P, c_int, P],
+    'vp_sumsq_chunks_det': [P, P, P, c_int, P, P, c_int, P],
+    'vp_drop_path_scales': [P, P, c_int, c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, P],
+    'vp_scale_bf16': [P, c_size_t, P, P],
+    'vp_zero': [P, c_size_t, P],
+    'vp_pos_embed_grad': [P, P, c_int, c_int, c_int, P],
     'vp_adamw_step': [P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_float, c_int, P,
                       c_float, c_float, P],
 }

@@ -98,6 +98,9 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
         model = model.module
     ckpt = {'meta': meta,
             'state_dict': OrderedDict((k, v.detach().cpu().clone()) for k, v in model.state_dict().items())}
-    if optimizer is not None and hasattr(optimizer, 'state_dict'):
+    if optimizer is not None:
+        if not hasattr(optimizer, 'state_dict'):
+            raise TypeError(f'{type(optimizer).__name__} has no state_dict(): its state cannot be saved '
+                            '(pass optimizer=None to save the weights alone)')
         ckpt['optimizer'] = optimizer.state_dict()
     torch.save(ckpt, filename)

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_batched_kernel(const vp_l
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc += red[r][cx];
         float* dst = j < E ? t.dgamma : (j < 2 * E ? t.dbeta : t.dcolsum);
-        if (dst) dst[j % E] += acc;
+        if (dst) dst[j % E] = t.overwrite ? acc : dst[j % E] + acc;
     }
 }
 

@@ -296,6 +296,99 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// the same over a chunk table (the optimizer's: {start, length} in elements, lengths multiples of 4): workgroup b
+// takes chunks b, b + gridDim.x, ... -- a fixed assignment, so the sum has a fixed order
+__global__ __launch_bounds__(256) void sumsq_chunks_partial_kernel(const float* __restrict__ x,
+                                                                   const long* __restrict__ chunk_start,
+                                                                   const int* __restrict__ chunk_len, int nchunks,
+                                                                   float* __restrict__ partial) {
+    float s = 0.f;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const float* p = x + chunk_start[c];
+        const int len = chunk_len[c];
+        for (int i = threadIdx.x * 4; i < len; i += 256 * 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_assign_kernel(const float* __restrict__ partial, int n,
+                                                           float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+// Philox-4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter-based, so element i of
+// step `ctr` is a pure function of (seed, ctr, i)
+__device__ __forceinline__ uint32_t philox_first(uint64_t seed, uint64_t ctr, uint32_t idx) {
+    uint32_t c0 = idx, c1 = 0, c2 = (uint32_t)ctr, c3 = (uint32_t)(ctr >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// DropPath scales of one step: dp[i][j][b] = floor(keep_i + U) / keep_i, keep_i = 1 - rates[i]; rate 0 (Block 0, a
+// Block in eval mode) gives exactly 1
+__global__ __launch_bounds__(256) void drop_path_kernel(float* __restrict__ dp, const float* __restrict__ rates,
+                                                        int per_block, int total, uint64_t seed, uint64_t ctr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float keep = 1.f - rates[i / per_block];
+    const float u = (float)(philox_first(seed, ctr, (uint32_t)i) >> 8) * (1.0f / 16777216.0f);   // [0, 1), 24 bits
+    dp[i] = keep >= 1.f ? 1.f : floorf(keep + u) / keep;
+}
+
+__global__ __launch_bounds__(256) void scale_bf16_kernel(bf16* __restrict__ x, size_t n8, const float* __restrict__ scale) {
+    const float s = *scale;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        bf16x8 v = *reinterpret_cast<bf16x8*>(x + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * s);
+        *reinterpret_cast<bf16x8*>(x + i * 8) = v;
+    }
+}
+
+// row 0 of a [1 + T][E] position-embedding gradient: the sum of rows 1 .. T (vit.py:320 adds pos_embed[:, :1]
+// to every token)
+__global__ __launch_bounds__(256) void pos_row0_kernel(float* __restrict__ gpos, int T, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = 1;
+    for (; t + 3 <= T; t += 4) {
+        s0 += gpos[(size_t)t * E + e];
+        s1 += gpos[(size_t)(t + 1) * E + e];
+        s2 += gpos[(size_t)(t + 2) * E + e];
+        s3 += gpos[(size_t)(t + 3) * E + e];
+    }
+    for (; t <= T; ++t) s0 += gpos[(size_t)t * E + e];
+    gpos[e] = (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int n,
                                                           float* __restrict__ out) {
     __shared__ float red[256];
@@ -462,5 +555,45 @@ extern "C" int vp_adamw_step(float* p, const float* g, float* m, float* v, void*
 extern "C" int vp_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
     VP_CHECK_ARG(x && y && n > 0 && n % 4 == 0);
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, x, (bf16*)y, n / 4);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_sumsq_chunks_det(const float* x, const long* chunk_start, const int* chunk_len, int nchunks, float* out,
+                                   float* partials, int npartials, hipStream_t stream) {
+    VP_CHECK_ARG(x && chunk_start && chunk_len && nchunks > 0 && out && partials && npartials >= 1);
+    int blocks = npartials < 1024 ? npartials : 1024;
+    if (blocks > nchunks) blocks = nchunks;
+    hipLaunchKernelGGL(sumsq_chunks_partial_kernel, dim3(blocks), dim3(256), 0, stream, x, chunk_start, chunk_len, nchunks,
+                       partials);
+    hipLaunchKernelGGL(sumsq_assign_kernel, dim3(1), dim3(256), 0, stream, partials, blocks, out);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_drop_path_scales(float* dp, const float* rates, int depth, int per_block, unsigned long long seed,
+                                   unsigned long long counter, hipStream_t stream) {
+    VP_CHECK_ARG(dp && rates && depth > 0 && per_block > 0);
+    const int total = depth * per_block;
+    hipLaunchKernelGGL(drop_path_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dp, rates, per_block, total,
+                       (uint64_t)seed, (uint64_t)counter);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_scale_bf16(void* x, size_t n, const float* scale_dev, hipStream_t stream) {
+    VP_CHECK_ARG(x && scale_dev && n > 0 && n % 8 == 0 && ((uintptr_t)x & 15) == 0);
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (bf16*)x, n / 8, scale_dev);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_zero(void* p, size_t bytes, hipStream_t stream) {
+    VP_CHECK_ARG(p && bytes > 0);
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+    return e == hipSuccess ? VP_OK : (int)e;
+}
+
+extern "C" int vp_pos_embed_grad(const float* dx, float* gpos, int B, int T, int E, hipStream_t stream) {
+    VP_CHECK_ARG(dx && gpos && B > 0 && T > 0 && E > 0 && E % 4 == 0);
+    const int rc = vp_batch_sum_f32(dx, gpos + E, B, (size_t)T * E, stream);      // rows 1 .. T
+    if (rc != VP_OK) return rc;
+    hipLaunchKernelGGL(pos_row0_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, gpos, T, E);
     VP_LAUNCH_RET();
 }

@@ -140,6 +140,9 @@ def reduce_scalars(values: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def shard_batch(n_total: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous equal shards of the global batch (weak scaling: n_total = world * per_gpu)."""
+    """Contiguous equal shards of the global batch (weak scaling: n_total = world * per_gpu).  Equal shards are what
+    makes the averaged gradient the gradient of the global mean, so a remainder is an error, not a silent drop."""
+    if n_total % world:
+        raise ValueError(f'a global batch of {n_total} images does not split evenly over {world} ranks')
     per = n_total // world
     return rank * per, (rank + 1) * per

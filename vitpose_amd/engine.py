@@ -20,6 +20,7 @@ from . import _lib
 from .plan import Plan
 
 ALIGN = 64  # elements; keeps every tensor 256-byte aligned in the f32 buffers
+POISON_WORKSPACES = os.environ.get('VITPOSE_POISON_WORKSPACES', '0') == '1'
 
 
 def _round_up(n, a):
@@ -98,6 +99,8 @@ class Workspace:
         shape = tuple(int(s) for s in shape)
         if t is None or t.shape != shape or t.dtype != dtype:
             t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            if POISON_WORKSPACES and not zero and t.is_floating_point():
+                t.fill_(float('nan'))       # debugging aid: a kernel that reads a buffer nobody wrote shows up as NaN
             self.bufs[key] = t
         return t
 
@@ -206,9 +209,12 @@ class VitRunner:
             raise NotImplementedError('channel counts must be multiples of 64')
         dev = store.device
         self.pos_comb = torch.empty(self.T, self.E, dtype=torch.float32, device=dev)
-        self.dpos = torch.empty(self.T, self.E, dtype=torch.float32, device=dev)
         rates = torch.linspace(0, cfg.get('drop_path_rate', 0.), self.depth)
         self.dp_rates = [r.item() for r in rates]
+        # per-Block rates the sampling kernel reads (a Block in eval mode -- frozen_stages -- samples nothing: 0)
+        self.dp_rates_dev = torch.tensor(self.dp_rates, dtype=torch.float32, device=dev)
+        self._dp_active = tuple([True] * self.depth)
+        self._dp_counter = 0
         # mixture-of-experts FFN (ViTMoE): the last `part` output channels of fc2 come from the expert Linear of
         # the image's dataset.  The GEMM kernels read the expert's rows `delta` elements beyond where the shared
         # matrix would hold them (offsets inside the flat parameter buffers, identical for f32 / bf16 / gradients).
@@ -276,11 +282,21 @@ class VitRunner:
         pe = self.w('pos_embed')[0]
         torch.add(pe[1:], pe[:1], out=self.pos_comb)
 
-    def sample_drop_path(self, dp: torch.Tensor, generator=None):
-        """Fill dp [depth][2][B] with per-sample DropPath scales floor(keep + U) / keep."""
-        u = torch.rand(dp.shape, device=dp.device, generator=generator)
-        keep = 1.0 - torch.tensor(self.dp_rates, device=dp.device).view(-1, 1, 1)
-        torch.div(torch.floor(keep + u), keep, out=dp)
+    def sample_drop_path(self, dp: torch.Tensor, active=None):
+        """Fill dp [depth][2][B] with per-sample DropPath scales floor(keep + U) / keep (one HIP launch; U from a
+        counter-based generator keyed by torch's seed and a step counter).  active: per-Block flags -- a Block whose
+        module is in eval mode (vit.py:249-284 puts frozen stages there) keeps scale 1."""
+        import ctypes
+        active = tuple(bool(a) for a in active) if active is not None else tuple([True] * self.depth)
+        if active != self._dp_active:
+            self.dp_rates_dev.copy_(torch.tensor([r if a else 0.0 for r, a in zip(self.dp_rates, active)]))
+            self._dp_active = active
+        self._dp_counter += 1
+        rc = _lib.lib().vp_drop_path_scales(dp.data_ptr(), self.dp_rates_dev.data_ptr(), self.depth, dp[0].numel(),
+                                            torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, self._dp_counter,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f'vp_drop_path_scales failed with status {rc}')
 
     # -- forward --
     def record_forward(self, plan: Plan, ws: Workspace, img: torch.Tensor, B: int, training: bool,
@@ -454,6 +470,7 @@ class VitRunner:
             if G <= 0:
                 plan.wgrad(x, y, self.g(name), Mw, Nw, M, ldx=Mw, ldy=Nw, split_k=_split_k(Mw, Nw, M), slab=slab)
                 if bias is not None:
+                    plan.memset0(self.g(bias))
                     plan.colsum(x, self.g(bias), M, Mw, Mw)
             else:
                 # the grouped kernel sums the columns of x on the side (one extra MFMA per fragment)
@@ -461,7 +478,8 @@ class VitRunner:
 
         def flush():
             if ln_pending:
-                plan.ln_finalize(list(ln_pending), M, E)
+                # every target receives exactly one sum per pass: stored, not added (no zeroed gradient buffer needed)
+                plan.ln_finalize(list(ln_pending), M, E, overwrite=True)
                 ln_pending.clear()
             if pending:
                 plan.fork()
@@ -539,13 +557,7 @@ class VitRunner:
             pslab = ws.f32('splitk_slab_patch', 32 * E * self.Kpe)
             plan.wgrad(dxb, ws.bufs['pe_col'], self.g('patch_embed.proj.weight'), E, self.Kpe, M, ldx=E, ldy=self.Kpe,
                        split_k=_split_k(E, self.Kpe, M), slab=pslab)
-        plan.batch_sum(dx, self.dpos, B, T * E)
-        gp = self.g('pos_embed')[0]
-
-        def pos_grad():
-            # pos_embed grad: rows 1.. per token, row 0 broadcast over tokens ([T][E] adds: plumbing)
-            gp[1:] += self.dpos
-            gp[0] += self.dpos.sum(0)
-        plan.host(pos_grad)
+        # pos_embed gradient: rows 1 .. T = sum over images of dx, row 0 (added to every token) = their sum
+        plan.pos_embed_grad(dx, self.g('pos_embed')[0], B, T, E)
         plan.join()
         self._dx0 = dx

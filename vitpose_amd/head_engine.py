@@ -325,6 +325,7 @@ class HeadRunner:
     def _record_backward_simple(self, plan, ws, feat, dpred, B):
         """dpred: NCHW f32 gradient wrt the heat maps."""
         M, C = B * self.Hg * self.Wg, self.cin
+        plan.memset0(self.g('final_layer.bias'))       # vp_plane_sum_f32 accumulates
         plan.plane_sum(dpred, self.g('final_layer.bias'), B, self.K, self.Ho * self.Wo)
         dG = ws.bf16('upconv_dG', M, self.ngp)
         plan.upconv_bwd(dpred, dG, self.ngp, self.ttabs, B, self.K, self.kp, self.Hg, self.Wg, self.Ho, self.Wo,
@@ -332,11 +333,8 @@ class HeadRunner:
         slab = ws.f32('splitk_slab_head', _slab_elems(self.ngp * C, M))
         plan.wgrad(dG, self._relu_feat, self.dwcat, self.ngp, C, M, ldx=self.ngp, ldy=C,
                    split_k=_split_k(self.ngp, C, M), slab=slab)
-        gW, dwcat, K, kp, taps, fk = self.g('final_layer.weight'), self.dwcat, self.K, self.kp, self.taps, self.fk
-
-        def final_grads():
-            gW.add_(dwcat[:taps * kp].view(taps, kp, C)[:, :K].permute(1, 2, 0).reshape(K, C, fk, fk))
-        plan.host(final_grads)
+        # dwcat[t * kp + k][c] -> the parameter's [k][c][tap t] (stored)
+        plan.strided_cast(self.dwcat, self.g('final_layer.weight'), (self.K, C, self.taps, 1), (C, 1, self.kp * C, 0))
         g = ws.bf16('hg', M, C)
         if self.upsample > 0:
             plan.gemm(dG, self.wcat, g, M, C, self.ngp, ldx=self.ngp, ldy=C, ldo=C, y_kmajor=True,
@@ -368,12 +366,10 @@ class HeadRunner:
         plan.memset0(self.dbf)
         plan.wgrad(dheat, a_last, self.dwf, self.kpad, cl, Mh, ldx=self.kpad, ldy=cl, split_k=_split_k(self.kpad, cl, Mh), slab=slab)
         plan.colsum(dheat, self.dbf, Mh, self.kpad, self.kpad)
-        gW, gb, dwf, dbf, K = self.g('final_layer.weight'), self.g('final_layer.bias'), self.dwf, self.dbf, self.K
-
-        def final_grads():
-            gW.view(K, -1).add_(dwf[:K])
-            gb.add_(dbf[:K])
-        plan.host(final_grads)
+        # the first K rows of the padded gradients are the final layer's (stored: no zeroed gradient buffer needed)
+        gW, gb, K = self.g('final_layer.weight'), self.g('final_layer.bias'), self.K
+        plan.strided_cast(self.dwf, gW, (1, 1, 1, gW.numel()), (0, 0, 0, 1))
+        plan.strided_cast(self.dbf, gb, (1, 1, 1, K), (0, 0, 0, 1))
         g = ws.bf16('hg', Mh, cl)
         if self.nl == 0:
             plan.gemm(dheat, self.wf, g, Mh, cl, self.kpad, ldx=self.kpad, ldy=cl, ldo=cl, y_kmajor=True)
@@ -386,6 +382,8 @@ class HeadRunner:
             Mout, Min = B * H * W, B * Hi * Wi
             bn = f'deconv_layers.{3 * l + 1}.'
             dz = ws.bf16('hdz', Mout, co)
+            plan.memset0(self.g(bn + 'weight'))        # vp_bn_bwd accumulates its parameter gradients
+            plan.memset0(self.g(bn + 'bias'))
             plan.bn_bwd(g, ws.bufs[f'z.{l}'], self.bn_mean[l], self.bn_invstd[l], self.w(bn + 'weight'),
                         self.g(bn + 'weight'), self.g(bn + 'bias'), dz, Mout, co)
             a_in = ws.bufs[f'a.{l - 1}'] if l > 0 else feat
@@ -399,12 +397,8 @@ class HeadRunner:
                 plan.deconv_out_gather16(dz, G, B, Hi, Wi, co)
                 plan.wgrad(a_in, G, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=16 * co,
                            split_k=_split_k(ci, 16 * co, Min), slab=slab)
-            gw, dwd = self.g(f'deconv_layers.{3 * l}.weight'), self.dwd[l]
-
-            def wgrad(gw=gw, dwd=dwd, ci=ci, co=co):
-                # [ci][(ky,kx)][co] -> [ci][co][ky][kx]
-                gw.add_(dwd.view(ci, 16, co).permute(0, 2, 1).reshape(gw.shape))
-            plan.host(wgrad)
+            # [ci][(ky, kx)][co] -> the parameter's [ci][co][ky][kx] (stored)
+            plan.strided_cast(self.dwd[l], self.g(f'deconv_layers.{3 * l}.weight'), (ci, co, 16, 1), (16 * co, 1, co, 0))
             # data gradient wrt the layer input: G Wd^T  (+ ReLU mask of the previous activation)
             gin = ws.bf16('hg_in' if l % 2 else 'hg_in2', Min, ci)
             if co % 64 == 0 and FUSED_DECONV:

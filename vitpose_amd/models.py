@@ -314,7 +314,6 @@ class ViT(_FlatBound):
                 io['dfeat'] = ws.f32('dfeat_nchw', B, vr.E, vr.Hp, vr.Wp)
                 dcl = ws.bf16('dfeat_cl', B * vr.T, vr.E)
                 bwd = Plan()
-                bwd.memset0(self._grad_slice())
                 bwd.nchw_to_cl(io['dfeat'], dcl, B, vr.E, vr.T, vr.E)
                 vr.record_backward(bwd, ws, dcl, B, dp=dp)
             self._plans[key] = (fwd, bwd, io)
@@ -333,7 +332,7 @@ class ViT(_FlatBound):
             vr.set_routing(self._runners[('ws', keep)], B, src if src is not None else [0] * B)
         if keep:
             if self.training and max(vr.dp_rates) > 0:
-                vr.sample_drop_path(io['dp'])
+                vr.sample_drop_path(io['dp'], active=[blk.training for blk in self.blocks])
             else:
                 io['dp'].fill_(1.0)
         fwd.run()
@@ -871,7 +870,6 @@ class TopdownHeatmapSimpleHead(_FlatBound):
                 io['dheat'] = ws.f32('dheat_in', B, hr.K, *hr.out_grid)
                 io['dx'] = ws.f32('dx_nchw', B, C, H, W)
                 bwd = Plan()
-                bwd.memset0(self._grad_slice())
                 g = hr.record_backward_nchw(bwd, ws, io['feat'], io['dheat'], B)
                 bwd.strided_cast(g, io['dx'], (B, C, H * W, 1), (H * W * C, 1, C, 0))
             self._plans[key] = (fwd, bwd, io)
@@ -1042,7 +1040,9 @@ class TopDown(nn.Module):
             m._store, m._prefix, m._seen_version = st, pre, None
         self._grad_views = [(p, st.gview(n)) for n, p in self.named_parameters()]
         self._engine = eng
-        self._seen_version = None
+        # bf16 mirror and re-laid-out weights follow the f32 masters from the start (the engine is usable directly)
+        eng.refresh_weights()
+        self._seen_version = _param_versions(self.parameters())
 
     def _refresh(self):
         v = _param_versions(self.parameters())
@@ -1058,7 +1058,7 @@ class TopDown(nn.Module):
         eng.load_batch(io, img, target, tw, self._src)
         vr = eng.vit
         if self.backbone.training and max(vr.dp_rates) > 0:
-            vr.sample_drop_path(io['dp'])
+            vr.sample_drop_path(io['dp'], active=[blk.training for blk in self.backbone.blocks])
         else:
             io['dp'].fill_(1.0)
         self._stash = self._stash_live()
@@ -1083,9 +1083,10 @@ class TopDown(nn.Module):
         eng = self._engine
         plan, io = eng._train_plan(B)
         # every parameter gradient is linear in the heat-map gradient the forward half left behind:
-        # seeding with the incoming dL/dloss there costs one small device op and no host sync
+        # seeding with the incoming dL/dloss there costs one small kernel and no host sync
+        gs = g.reshape(-1).float()
         for j, dh in enumerate(io['dheats']):
-            dh.mul_((g[j] if g.dim() else g).to(dh.dtype))
+            eng.scale_dheat(dh, gs[j:j + 1] if gs.numel() > 1 else gs)
         plan.run(first=eng.n_fwd_calls)
         st = eng.store
         if self._stash is not None:
@@ -1353,3 +1354,9 @@ class _FlatOptimizer:
         # the kernel updates the master weights and their bf16 mirror in place (below torch's version
         # counters), and optimizer_step re-derives the re-laid-out head weights / combined pos-embed
         self.model._engine.optimizer_step(lr)
+
+    def state_dict(self):
+        return self.model._engine.optimizer.state_dict()
+
+    def load_state_dict(self, sd):
+        self.model._engine.optimizer.load_state_dict(sd)

@@ -59,6 +59,7 @@ class FlatAdamW:
         self.store, self.lr, self.betas, self.eps = store, lr, betas, eps
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
+        self.frozen = tuple(frozen)
         dev = store.device
         starts, lens, scales, wds = [], [], [], []
         for name in store.names:
@@ -94,11 +95,14 @@ class FlatAdamW:
         self.step_count += 1
         gn = None
         if self.max_grad_norm > 0:
-            self.gnorm_sq.zero_()
-            rc = L.vp_sumsq_f32_det(c_void_p(st.grad.data_ptr()), st.numel, c_void_p(self.gnorm_sq.data_ptr()),
-                                    c_void_p(self.gnorm_partials.data_ptr()), self.gnorm_partials.numel(), s)
+            # the norm runs over the optimizer's own chunks: parameters it does not update (frozen ones) stay out of
+            # the clip factor, as torch's clip_grad_norm_ over the parameters with requires_grad leaves them out
+            rc = L.vp_sumsq_chunks_det(c_void_p(st.grad.data_ptr()), c_void_p(self.chunk_start.data_ptr()),
+                                       c_void_p(self.chunk_len.data_ptr()), self.nchunks,
+                                       c_void_p(self.gnorm_sq.data_ptr()), c_void_p(self.gnorm_partials.data_ptr()),
+                                       self.gnorm_partials.numel(), s)
             if rc:
-                raise RuntimeError(f'vp_sumsq_f32_det failed: {rc}')
+                raise RuntimeError(f'vp_sumsq_chunks_det failed: {rc}')
             gn = c_void_p(self.gnorm_sq.data_ptr())
         rc = L.vp_adamw_step(
             c_void_p(st.data.data_ptr()), c_void_p(st.grad.data_ptr()), c_void_p(self.exp_avg.data_ptr()),
@@ -109,3 +113,36 @@ class FlatAdamW:
             self.max_grad_norm, grad_scale, s)
         if rc:
             raise RuntimeError(f'vp_adamw_step failed: {rc}')
+
+    # -- checkpointing (the reference saves optimizer.state_dict() next to the weights,
+    #    mmcv_custom/checkpoint.py:490-552; runner.resume restores it) --
+    def state_dict(self):
+        """Adam moments per parameter NAME (CPU tensors) + the step count and hyper-parameters."""
+        st = self.store
+        names = [n for n in st.names if n not in self.frozen]
+        return {'format': 'vitpose_amd.FlatAdamW/1', 'step': self.step_count,
+                'hyper': dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, max_grad_norm=self.max_grad_norm),
+                'state': {n: {'exp_avg': st._v(self.exp_avg, n).detach().cpu().clone(),
+                              'exp_avg_sq': st._v(self.exp_avg_sq, n).detach().cpu().clone()} for n in names}}
+
+    def load_state_dict(self, sd):
+        if sd.get('format') != 'vitpose_amd.FlatAdamW/1':
+            raise ValueError('not a FlatAdamW state dict (expected format "vitpose_amd.FlatAdamW/1")')
+        st = self.store
+        names = [n for n in st.names if n not in self.frozen]
+        missing = [n for n in names if n not in sd['state']]
+        unexpected = [n for n in sd['state'] if n not in names]
+        if missing or unexpected:
+            raise KeyError(f'optimizer state does not match the model: missing {missing[:3]}, unexpected {unexpected[:3]}')
+        for n in names:
+            for key, buf in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+                v = sd['state'][n][key]
+                if tuple(v.shape) != tuple(st.shapes[n]):
+                    raise ValueError(f'{n}.{key}: shape {tuple(v.shape)} != {tuple(st.shapes[n])}')
+                st._v(buf, n).copy_(v.to(st.device, torch.float32))
+        self.step_count = int(sd['step'])
+        h = sd.get('hyper', {})
+        self.lr = h.get('lr', self.lr)
+        self.betas = tuple(h.get('betas', self.betas))
+        self.eps = h.get('eps', self.eps)
+        self.max_grad_norm = h.get('max_grad_norm', self.max_grad_norm)

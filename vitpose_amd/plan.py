@@ -102,11 +102,12 @@ class Plan:
         self.side_calls = set()
 
     # -- replay --
-    def run(self, stream=None, first=0, last=None):
-        """Replay calls [first, last) on `stream` (default: torch's current HIP stream)."""
-        if self.timers is not None and stream is None:
+    def run(self, first=0, last=None):
+        """Replay calls [first, last) on torch's current HIP stream (set another with torch.cuda.stream(...): the
+        host-side entries of a plan -- events, forks -- follow the current stream too)."""
+        if self.timers is not None:
             return self.run_timed(self.timers, first, last)
-        s = c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+        s = c_void_p(torch.cuda.current_stream().cuda_stream)
         if not self.side_calls:
             calls = self.calls if first == 0 and last is None else self.calls[first:last]
             for name, fn, args in calls:
@@ -238,7 +239,8 @@ class Plan:
         a.rows_per_scale, a.ldaux, a.pos_rows, a.split_k = rows_per_scale, ldaux, pos_rows, split_k
         if row_map is not None:
             a.out_row_div, a.out_row_hi, a.out_row_lo, a.out_row_off = row_map
-        if self.use_tail_split and epilogue != _lib.VP_EPI_SPLITK_F32 and not split3:
+        if self.use_tail_split and epilogue != _lib.VP_EPI_SPLITK_F32 and not split3 and not self._side:
+            # (one scratch per device: safe for stream-ordered launches only, so side-stream calls go without)
             tw = _tail_workspace(out.device)
             a.tail_ws, a.tail_ws_bytes = tw.data_ptr(), tw.numel() * 4
             self.keep.append(tw)
@@ -379,9 +381,10 @@ class Plan:
                   workspace.numel(),
                   keep=(dy, x, mean, rstd, gamma, dres, dx, dxb, rowscale, dgamma, dbeta, dcolsum, workspace))
 
-    def ln_finalize(self, entries, M, E):
+    def ln_finalize(self, entries, M, E, overwrite=False):
         """One launch that adds the column sums several layernorm_bwd calls left in their workspaces (recorded with
-        dgamma = dbeta = dcolsum = None) to their targets.  entries: [(workspace, dgamma, dbeta, dcolsum)]."""
+        dgamma = dbeta = dcolsum = None) to their targets -- or, with `overwrite`, stores them there (every target then
+        needs no zeroing).  entries: [(workspace, dgamma, dbeta, dcolsum)]."""
         from ._lib import LnPartial
         if not entries:
             return
@@ -390,6 +393,7 @@ class Plan:
             _chk(wsp, torch.float32, 'workspace')
             t.partial = wsp.data_ptr()
             t.blocks = self.L.vp_layernorm_bwd_blocks(M, E, wsp.numel())
+            t.overwrite = int(overwrite)
             t.dgamma, t.dbeta, t.dcolsum = (x.data_ptr() if x is not None else None for x in (dg, db, dc))
         blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(entries[0][0].device)
         self._add('vp_layernorm_bwd_finalize', _p(blob), len(entries), E,
@@ -526,20 +530,18 @@ class Plan:
         self.calls.append(('host', _Host(fn), ()))
 
     def memset0(self, t):
-        """Zero a tensor on the plan's stream (torch's memset: plumbing, not compute)."""
-        if self._side:
-            return self.host(t.zero_)
-        self.calls.append(('zero_', _Zero(t), ()))
-        self.keep.append(t)
+        """Zero a (contiguous) tensor on the stream the call is launched on."""
+        assert t.is_contiguous()
+        self._add('vp_zero', _p(t), t.numel() * t.element_size(), keep=(t,))
 
+    def scale_bf16(self, x, scale):
+        """x (bf16) *= scale[0] (a device scalar)."""
+        _chk(x, torch.bfloat16, 'x'), _chk(scale, torch.float32, 'scale')
+        self._add('vp_scale_bf16', _p(x), x.numel(), _p(scale), keep=(x, scale))
 
-class _Zero:
-    def __init__(self, t):
-        self.t = t
-
-    def __call__(self, _stream):
-        self.t.zero_()
-        return 0
+    def pos_embed_grad(self, dx, gpos, B, T, E):
+        _chk(dx, torch.float32, 'dx'), _chk(gpos, torch.float32, 'gpos')
+        self._add('vp_pos_embed_grad', _p(dx), _p(gpos), B, T, E, keep=(dx, gpos))
 
 
 class _Host:

@@ -172,7 +172,7 @@ class PoseEngine:
             plan = Plan()
             if self.side_stream_wgrad:
                 plan.enable_side_stream(self.device)
-            plan.memset0(self.store.grad)
+            # (no gradient memset: every element of store.grad is stored by exactly one kernel of the backward half)
             feat = self.vit.record_forward(plan, ws, io['img'], B, training=True, dp=io['dp'])
             dheats = []
             for j, (h, hw) in enumerate(zip(self.heads, self.ws_heads)):
@@ -210,6 +210,18 @@ class PoseEngine:
             self.plans[key] = (plan, io)
         return self.plans[key]
 
+    def scale_dheat(self, dheat: torch.Tensor, scale: torch.Tensor):
+        """dheat *= scale[0] (device scalar): the incoming dL/dloss of an autograd backward.  Heat-map gradients are
+        bf16 channels-last (classic head) or f32 NCHW (simple decoder)."""
+        import ctypes
+        if dheat.dtype != torch.bfloat16:
+            dheat.mul_(scale)
+            return
+        rc = _lib.lib().vp_scale_bf16(dheat.data_ptr(), dheat.numel(), scale.data_ptr(),
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f'vp_scale_bf16 failed with status {rc}')
+
     def load_batch(self, io, img, target, target_weight, dataset_source=None):
         """Copy one batch into the plan's input buffers; with several heads / a routed backbone also the
         per-head selections of TopDownMoE.forward_train (top_down_moe.py:177-197): head j is trained on the
@@ -232,7 +244,7 @@ class PoseEngine:
             torch.mul(tw0, sel.view(B, 1), out=io['tws'][j])
 
     def forward_backward(self, img, target, target_weight, drop_path: bool = True, dp_scales=None,
-                         generator=None, timers=None, dataset_source=None):
+                         timers=None, dataset_source=None):
         """One training forward + backward.  Gradients land in self.store.grad (zeroed first);
         returns (loss [1] device tensor, heatmaps [B,K,H,W] device tensor; both are plan-owned) -- with
         associate heads, the lists of both over the heads."""
@@ -244,7 +256,7 @@ class PoseEngine:
         if dp_scales is not None:
             io['dp'].copy_(dp_scales)
         elif drop_path and max(self.vit.dp_rates) > 0:
-            self.vit.sample_drop_path(io['dp'], generator)
+            self.vit.sample_drop_path(io['dp'])
         else:
             io['dp'].fill_(1.0)
         if timers is not None:
