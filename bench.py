@@ -243,7 +243,7 @@ def main():
 
         def step():
             losses = model.forward_train(img, target, tw, metas)
-            loss = sum(losses[k] for k in loss_keys)
+            loss = losses[loss_keys[0]] if len(loss_keys) == 1 else sum(losses[k] for k in loss_keys)
             loss.backward()
             opt.step()
             opt.zero_grad()

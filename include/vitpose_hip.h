@@ -412,6 +412,13 @@ int vp_drop_path_scales(float* dp, const float* rates, int depth, int per_block,
 int vp_scale_bf16(void* x, size_t n, const float* scale_dev, vp_stream_t stream);
 /* hipMemsetAsync(p, 0, bytes) on `stream` (accumulating reductions start from zero). */
 int vp_zero(void* p, size_t bytes, vp_stream_t stream);
+/* Up to VP_ZERO_MAX_REGIONS small f32 regions zeroed by one launch (BatchNorm sums and parameter gradients, the
+ * loss scalar ...).  ptrs_host / floats_host are HOST arrays (copied into the kernel arguments). */
+#define VP_ZERO_MAX_REGIONS 16
+int vp_zero_regions(float* const* ptrs_host, const int* floats_host, int count, vp_stream_t stream);
+/* out[t][e] = pos_embed[1 + t][e] + pos_embed[0][e] (vit.py:320: x + pos_embed[:, 1:] + pos_embed[:, :1]), the
+ * [T][E] table the patch-embedding epilogue adds; recomputed after every weight update. */
+int vp_pos_combine(const float* pos_embed, float* out, int T, int E, vp_stream_t stream);
 /* Gradient of pos_embed [1][1 + T][E] from the gradient dx [B][T][E] of the embedded tokens (vit.py:320:
  * x + pos_embed[:, 1:] + pos_embed[:, :1]): rows 1 .. T = sum over images, row 0 = sum of those rows.  Overwrites. */
 int vp_pos_embed_grad(const float* dx, float* gpos, int B, int T, int E, vp_stream_t stream);

@@ -104,6 +104,8 @@ SIGNATURES = {
     'vp_drop_path_scales': [P, P, c_int, c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, P],
     'vp_scale_bf16': [P, c_size_t, P, P],
     'vp_zero': [P, c_size_t, P],
+    'vp_zero_regions': [P, P, c_int, P],
+    'vp_pos_combine': [P, P, c_int, c_int, P],
     'vp_pos_embed_grad': [P, P, c_int, c_int, c_int, P],
     'vp_adamw_step': [P, P, P, P, P, P, P, P, P, c_int, c_float, c_float, c_float, c_float, c_int, P,
                       c_float, c_float, P],

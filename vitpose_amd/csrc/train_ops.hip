@@ -362,6 +362,29 @@ __global__ __launch_bounds__(256) void drop_path_kernel(float* __restrict__ dp, 
     dp[i] = keep >= 1.f ? 1.f : floorf(keep + u) / keep;
 }
 
+// several small accumulators zeroed by ONE launch (a memset node per region costs ~5 us of launch each)
+struct ZeroRegions {
+    float* p[VP_ZERO_MAX_REGIONS];
+    int n[VP_ZERO_MAX_REGIONS];       // floats
+    int count;
+};
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroRegions r) {
+    float* p = r.p[blockIdx.y];
+    const int n = r.n[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// out[t][e] = a[1 + t][e] + a[0][e]: the position table every token row receives (vit.py:320)
+__global__ __launch_bounds__(256) void pos_combine_kernel(const float* __restrict__ pe, float* __restrict__ out, int T,
+                                                          int E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T * E) out[i] = pe[E + i] + pe[i % E];
+}
+
+__global__ void add_i64_kernel(long long** p, int count, long long v) {
+    if ((int)threadIdx.x < count) *p[threadIdx.x] += v;
+}
+
 __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16* __restrict__ x, size_t n8, const float* __restrict__ scale) {
     const float s = *scale;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -595,5 +618,28 @@ extern "C" int vp_pos_embed_grad(const float* dx, float* gpos, int B, int T, int
     const int rc = vp_batch_sum_f32(dx, gpos + E, B, (size_t)T * E, stream);      // rows 1 .. T
     if (rc != VP_OK) return rc;
     hipLaunchKernelGGL(pos_row0_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, gpos, T, E);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_zero_regions(float* const* ptrs_host, const int* floats_host, int count, hipStream_t stream) {
+    VP_CHECK_ARG(ptrs_host && floats_host && count > 0 && count <= VP_ZERO_MAX_REGIONS);
+    ZeroRegions r{};
+    int mx = 0;
+    for (int i = 0; i < count; ++i) {
+        VP_CHECK_ARG(ptrs_host[i] && floats_host[i] > 0);
+        r.p[i] = ptrs_host[i];
+        r.n[i] = floats_host[i];
+        mx = floats_host[i] > mx ? floats_host[i] : mx;
+    }
+    r.count = count;
+    int gx = (mx + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(gx, count), dim3(256), 0, stream, r);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_pos_combine(const float* pos_embed, float* out, int T, int E, hipStream_t stream) {
+    VP_CHECK_ARG(pos_embed && out && T > 0 && E > 0);
+    hipLaunchKernelGGL(pos_combine_kernel, dim3((T * E + 255) / 256), dim3(256), 0, stream, pos_embed, out, T, E);
     VP_LAUNCH_RET();
 }

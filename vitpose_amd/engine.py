@@ -279,8 +279,10 @@ class VitRunner:
 
     def refresh_derived(self):
         """Weight-derived constants (after every weight update)."""
-        pe = self.w('pos_embed')[0]
-        torch.add(pe[1:], pe[:1], out=self.pos_comb)
+        if getattr(self, '_derived_plan', None) is None:
+            self._derived_plan = Plan()
+            self._derived_plan.pos_combine(self.w('pos_embed')[0], self.pos_comb, self.T, self.E)
+        self._derived_plan.run()
 
     def sample_drop_path(self, dp: torch.Tensor, active=None):
         """Fill dp [depth][2][B] with per-sample DropPath scales floor(keep + U) / keep (one HIP launch; U from a

@@ -171,8 +171,7 @@ class HeadRunner:
                                     self.chans[l], self.chans[l + 1])
         Wf = self.w('final_layer.weight')  # [K][C][1][1]
         plan.strided_cast(Wf, self.wf, (1, 1, 1, Wf.numel()), (0, 0, 0, 1))
-        bf, b = self.bf, self.w('final_layer.bias')
-        plan.host(lambda: bf[:b.numel()].copy_(b))
+        plan.strided_cast(self.w('final_layer.bias'), self.bf, (1, 1, 1, self.K), (0, 0, 0, 1))
 
     # -- fp32-accurate evaluation: pair arrays of the compute-layout weights + the forward pass --
     def record_weight_prep_exact(self, plan: Plan):
@@ -253,6 +252,8 @@ class HeadRunner:
         H, W = self.Hg, self.Wg
         a = feat
         sfx = (lambda l: f'.{l}') if training else (lambda l: '')
+        # the accumulators of this pass (BatchNorm sums, the loss scalar) start from zero: one launch for all
+        plan.zero_small(([s_ for s_ in self.bn_sums] if training else []) + ([loss] if loss is not None else []))
         for l in range(self.nl):
             ci, co = self.chans[l], self.chans[l + 1]
             Min, Mout = B * H * W, B * 4 * H * W
@@ -279,7 +280,6 @@ class HeadRunner:
                                   bias=None if training else self.bn_shift[l],
                                   row_map=(W, 4 * W, 2, py * 2 * W + px))
             if training:
-                plan.memset0(self.bn_sums[l])
                 plan.bn_stats(z, self.bn_sums[l], Mout, co)
                 plan.bn_finalize(self.bn_sums[l], Mout, co, self.w(bn + 'weight'), self.w(bn + 'bias'),
                                  self.buf(bn + 'running_mean'), self.buf(bn + 'running_var'), 0.1, 1e-5,
@@ -295,8 +295,6 @@ class HeadRunner:
         heat = ws.f32('heat_cl', Mh, self.kpad)
         plan.gemm(a, self.wf, heat, Mh, self.kpad, cl, ldx=cl, ldy=cl, ldo=self.kpad, epilogue=_lib.VP_EPI_F32, bias=self.bf)
         dheat = ws.bf16('dheat', Mh, self.kpad) if want_grad else None
-        if loss is not None:
-            plan.memset0(loss)
         plan.heatmap_loss(heat, self.kpad, heat_nchw, target, tw, loss, dheat, B, self.K, H * W, loss_weight)
         self._last_act = a
         self.out_hw = (H, W)
@@ -363,7 +361,8 @@ class HeadRunner:
         # final 1x1 conv
         slab = ws.f32('splitk_slab_head', _slab_elems(max(self.chans[l] * 16 * self.chans[l + 1]
                                                           for l in range(self.nl)) if self.nl else self.kpad * cl, Mh))
-        plan.memset0(self.dbf)
+        # vp_colsum_bf16 and vp_bn_bwd accumulate: their targets start from zero (one launch)
+        plan.zero_small([self.dbf] + [self.g(f'deconv_layers.{3 * l + 1}.{k}') for l in range(self.nl) for k in ('weight', 'bias')])
         plan.wgrad(dheat, a_last, self.dwf, self.kpad, cl, Mh, ldx=self.kpad, ldy=cl, split_k=_split_k(self.kpad, cl, Mh), slab=slab)
         plan.colsum(dheat, self.dbf, Mh, self.kpad, self.kpad)
         # the first K rows of the padded gradients are the final layer's (stored: no zeroed gradient buffer needed)
@@ -382,8 +381,6 @@ class HeadRunner:
             Mout, Min = B * H * W, B * Hi * Wi
             bn = f'deconv_layers.{3 * l + 1}.'
             dz = ws.bf16('hdz', Mout, co)
-            plan.memset0(self.g(bn + 'weight'))        # vp_bn_bwd accumulates its parameter gradients
-            plan.memset0(self.g(bn + 'bias'))
             plan.bn_bwd(g, ws.bufs[f'z.{l}'], self.bn_mean[l], self.bn_invstd[l], self.w(bn + 'weight'),
                         self.g(bn + 'weight'), self.g(bn + 'bias'), dz, Mout, co)
             a_in = ws.bufs[f'a.{l - 1}'] if l > 0 else feat

@@ -836,6 +836,26 @@ class TopdownHeatmapSimpleHead(_FlatBound):
             raise NotImplementedError('resize_concat / multiple_select inputs are outside the HIP path')
         return inputs[self.in_index]
 
+    # BatchNorm2d.num_batches_tracked (a LongTensor buffer the reference's modules increment every training
+    # forward): counted on the host and added to the buffers when the state dict is read -- one device add per
+    # BatchNorm per step is pure launch overhead in the step
+    _bn_steps_pending = 0
+
+    def flush_bn_counters(self):
+        if self._bn_steps_pending:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                    m.num_batches_tracked += self._bn_steps_pending
+            self._bn_steps_pending = 0
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_bn_counters()
+        return super().state_dict(*args, **kwargs)
+
+    def _save_to_state_dict(self, *args, **kwargs):
+        self.flush_bn_counters()
+        return super()._save_to_state_dict(*args, **kwargs)
+
     # ---- HIP execution ----
     def _bn_buffers(self):
         return {self._prefix + n: b for n, b in self.named_buffers() if b.dtype == torch.float32}
@@ -891,9 +911,7 @@ class TopdownHeatmapSimpleHead(_FlatBound):
         io['x'].copy_(x)
         fwd.run()
         if keep and self.training:
-            for m in self.modules():
-                if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
-                    m.num_batches_tracked += 1
+            self._bn_steps_pending += 1
         return io['heat'].clone()
 
     def _run_backward(self, dheat, shape):
@@ -1065,9 +1083,7 @@ class TopDown(nn.Module):
         plan.run(first=0, last=eng.n_fwd_calls)
         for _, h in self._heads():
             if h.training:
-                for m in h.modules():
-                    if isinstance(m, nn.BatchNorm2d):
-                        m.num_batches_tracked += 1
+                h._bn_steps_pending += 1          # num_batches_tracked catches up when somebody looks (state_dict)
         self._heat, self._heats = io['heat'], io['heats']
         if len(io['losses']) > 1:
             return torch.cat(io['losses'])       # one loss per head

@@ -534,10 +534,36 @@ class Plan:
         assert t.is_contiguous()
         self._add('vp_zero', _p(t), t.numel() * t.element_size(), keep=(t,))
 
+    def zero_small(self, tensors):
+        """Zero several small f32 tensors with one launch (each a few KB at most)."""
+        tensors = [t for t in tensors if t is not None]
+        for i in range(0, len(tensors), 16):
+            grp = tensors[i:i + 16]
+            for t in grp:
+                _chk(t, torch.float32, 'zero_small')
+            ptrs = (c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+            sizes = (ctypes.c_int * len(grp))(*[t.numel() for t in grp])
+            self._add('vp_zero_regions', ptrs, sizes, len(grp), keep=(ptrs, sizes) + tuple(grp))
+
+    def rebind(self, old_ptr, new_ptr):
+        """Point every recorded pointer argument that equals `old_ptr` at `new_ptr` (an input buffer of the plan
+        replaced by the caller's own tensor of the same shape: saves the copy).  Returns the number of arguments
+        changed; the caller keeps the new tensor alive until the plan has run."""
+        n = 0
+        for _, _, args in self.calls:
+            for a in args:
+                if isinstance(a, c_void_p) and a.value == old_ptr:
+                    a.value = new_ptr
+                    n += 1
+        return n
+
     def scale_bf16(self, x, scale):
         """x (bf16) *= scale[0] (a device scalar)."""
         _chk(x, torch.bfloat16, 'x'), _chk(scale, torch.float32, 'scale')
         self._add('vp_scale_bf16', _p(x), x.numel(), _p(scale), keep=(x, scale))
+
+    def pos_combine(self, pos_embed, out, T, E):
+        self._add('vp_pos_combine', _p(pos_embed), _p(out), T, E, keep=(pos_embed, out))
 
     def pos_embed_grad(self, dx, gpos, B, T, E):
         _chk(dx, torch.float32, 'dx'), _chk(gpos, torch.float32, 'gpos')

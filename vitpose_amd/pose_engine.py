@@ -227,8 +227,22 @@ class PoseEngine:
         per-head selections of TopDownMoE.forward_train (top_down_moe.py:177-197): head j is trained on the
         images whose dataset index is j, every other image's target weights (and targets) are zeroed."""
         B = img.shape[0]
+        plan = self.plans[('train', B)][0]
+        bound = io.setdefault('_bound', {})
         for k, t in (('img', img), ('target', target), ('tw', target_weight.reshape(B, self.K))):
-            if t.data_ptr() != io[k].data_ptr():
+            cur = bound.get(k, io[k].data_ptr())
+            if t.data_ptr() == cur:
+                continue
+            if (not self.multi and t.dtype == torch.float32 and t.is_contiguous() and t.device == io[k].device
+                    and t.shape == io[k].shape and t.data_ptr() % 16 == 0):
+                # the caller's tensor has the plan's layout: the forward kernels read it in place (they are the only
+                # readers; stream order keeps the memory valid until they have run)
+                plan.rebind(cur, t.data_ptr())
+                bound[k] = t.data_ptr()
+            else:
+                if cur != io[k].data_ptr():
+                    plan.rebind(cur, io[k].data_ptr())
+                    bound.pop(k, None)
                 io[k].copy_(t)
         if not self.multi:
             return
