@@ -238,8 +238,10 @@ def main():
                  constructor='LayerDecayOptimizerConstructor',
                  paramwise_cfg=dict(num_layers=m['depth'], layer_decay_rate=m['layer_decay'])),
             grad_clip=dict(max_norm=1., norm_type=2))
+        comm = None
         if world > 1:
-            model.enable_ddp()
+            comm = model.enable_ddp()
+            comm.measure = True        # event pairs around the end-of-backward wait: exposed vs hidden all-reduce time
 
         def step():
             losses = model.forward_train(img, target, tw, metas)
@@ -261,6 +263,7 @@ def main():
                     f'global batch {world * B}, random-init weights')
     else:
         model.eval()
+        comm = None
 
         def step():
             with torch.no_grad():
@@ -284,6 +287,9 @@ def main():
     last = None
     for _ in range(max(1, args.warmup)):
         last = step()
+    if args.mode == 'train' and comm is not None:
+        torch.cuda.synchronize()
+        comm.exposed_ms()              # drop the warm-up records
     # one more untimed step with a HIP-event pair around EVERY GEMM launch: finds the dominant kernel
     survey = []
     plan_of().timers = survey
@@ -311,6 +317,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    comm_ms = comm.exposed_ms() if args.mode == 'train' and comm is not None else []
     plan_of().timers = None
     plan_of().timer_filter = None
     if world > 1:
@@ -358,6 +365,15 @@ def main():
         }
         if args.mode == 'train':
             out['loss'] = float(last.item())
+        if comm_ms:
+            ex, busy = sorted(e for e, _ in comm_ms), sorted(b for _, b in comm_ms)
+            out['allreduce'] = {
+                'exposed_ms_per_step_median': round(ex[len(ex) // 2], 3), 'exposed_ms_per_step_max': round(ex[-1], 3),
+                'busy_ms_per_step_median': round(busy[len(busy) // 2], 3),
+                'hidden_fraction': round(1.0 - ex[len(ex) // 2] / max(busy[len(busy) // 2], 1e-9), 3),
+                'gradient_bytes': int(eng.store.numel * (2 if comm.bf16 else 4)),
+                'note': 'rank 0; exposed = compute stream waiting for the gradient exchange after backward ended, busy = '
+                        'first bucket hand-over to last collective done (HIP events on the two streams)'}
         if world == 1 and not args.no_cpu_baseline and not args.plus:
             out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_batch, args.mode)
             out.update(parity_vs_oracle(eng, args.model, args.cpu_batch, dev))

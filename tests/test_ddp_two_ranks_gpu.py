@@ -65,7 +65,7 @@ def _worker(rank, world, port, q, bf16=False):
         w0 = eng.store.data.clone()
         eng.forward_backward(x, t, w, drop_path=False)
         torch.cuda.synchronize()
-        assert not comm.pending
+        assert comm.launched == 0 and not comm.staged
         got = eng.store.grad.clone()
         for n in eng.store.names:
             a, b = eng.store._v(got, n), eng.store._v(want, n)

@@ -329,7 +329,7 @@ def test_topdown_ddp_overlapped_rccl_path_from_the_autograd_thread(dev):
             opt.zero_grad()
             losses.append(out['heatmap_loss'].item())
         torch.cuda.synchronize()
-        assert not comm.pending and all(l == l for l in losses)
+        assert comm.launched == 0 and not comm.staged and all(l == l for l in losses)
         assert losses[-1] < losses[0], losses
     finally:
         if created:

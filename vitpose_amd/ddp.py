@@ -27,8 +27,11 @@ class GradBuckets:
         self.stream = torch.cuda.Stream(device=store.device) if self.on_gpu else None
         # asynchronous, stream-ordered collectives (overlapped with the rest of backward) exist with RCCL only
         self.overlap = self.on_gpu and dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
-        self.pending = []
-        self.ready_events = []
+        self.pending = []          # (kept for callers that look at it: always empty, no Work handles are held)
+        self.launched = 0          # collectives enqueued on the communication stream since the last wait()
+        self.measure = False       # True: wait() brackets itself with timing events (bench.py --gpus N)
+        self.timings = []
+        self._t_first = None
         # VITPOSE_DDP_BF16=1 (off by default: the reference all-reduces f32): the buckets travel as bf16 -- half the
         # bytes over xGMI -- and are widened back into the f32 gradient buffer once the collective is done
         self.bf16 = os.environ.get('VITPOSE_DDP_BF16', '0') == '1' and self.on_gpu
@@ -65,6 +68,13 @@ class GradBuckets:
         self.tail = (0, hi)
 
     # -- called from plan.host closures (i.e. in stream order of the compute stream) --
+    # RCCL path: everything is STREAM-ordered and issued by the one thread that replays the plan, in plan order
+    # (identical on every rank).  A bucket is handed to the communication stream by an event; the collective is
+    # enqueued there (torch's NCCL backend makes its own stream wait for the stream that is current at the call and
+    # makes that stream wait for the result: no Work handle is kept, nothing ever blocks the host); at the end of
+    # the plan the compute stream waits for ONE event recorded behind the last collective.  There is no host-side
+    # wait on communication and no second thread, so ranks cannot disagree on the order of collectives and a stalled
+    # peer shows up as a stalled stream (RCCL's watchdog), not as two hosts waiting for each other.
     def _launch(self, lo, hi):
         if self.world == 1 or hi <= lo:
             return
@@ -74,19 +84,21 @@ class GradBuckets:
             g = self.stage[lo:hi]
             self.staged.append((lo, hi))
         if self.on_gpu and not self.overlap:
-            # a backend other than RCCL (gloo, when several ranks rehearse on one GPU): its CUDA collectives block the
-            # host in wait(); issued asynchronously from the autograd thread they were seen to dead-lock after a few
-            # steps, so the bucket is reduced synchronously at its trigger point (no overlap; tests only)
+            # a backend other than RCCL (gloo, when several ranks rehearse on one GPU; tests only): reduced
+            # synchronously at the trigger point, no overlap
             torch.cuda.current_stream().synchronize()
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
             return
         if self.on_gpu:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            compute = torch.cuda.current_stream()
+            ev = torch.cuda.Event(enable_timing=self.measure and not self.launched)
+            ev.record(compute)
+            if self.measure and not self.launched:
+                self._t_first = ev
+            self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                self.stream.wait_event(ev)
-                w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append(w)
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            self.launched += 1
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -101,13 +113,32 @@ class GradBuckets:
         plan.host(self.wait)
 
     def wait(self):
-        """Make the compute stream wait for every outstanding bucket."""
-        for w in self.pending:
-            w.wait()
-        self.pending.clear()
+        """Make the compute stream wait for every outstanding bucket (no host wait)."""
+        if self.launched:
+            compute = torch.cuda.current_stream()
+            done = torch.cuda.Event(enable_timing=self.measure)
+            done.record(self.stream)                  # behind the last collective on the communication stream
+            if self.measure:
+                # exposed = what the compute stream spends in this wait; busy = first hand-over .. last collective done
+                before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                before.record(compute)
+                compute.wait_event(done)
+                after.record(compute)
+                self.timings.append((self._t_first, before, after, done))
+            else:
+                compute.wait_event(done)
+            self.launched = 0
         for lo, hi in self.staged:
             self._cast(self.stage, self.store.grad, lo, hi)
         self.staged.clear()
+
+    def exposed_ms(self):
+        """[(exposed, busy)] in ms per recorded step (call after a synchronize; needs measure = True): `exposed` is
+        the time the compute stream waited for the gradient exchange after backward had ended, `busy` the span from
+        the first bucket's hand-over to the completion of the last collective."""
+        out = [(b.elapsed_time(a), f.elapsed_time(d)) for f, b, a, d in self.timings]
+        self.timings.clear()
+        return out
 
     def _cast(self, src, dst, lo, hi):
         """dst[lo:hi] = (cast) src[lo:hi] on the current stream (f32 <-> bf16; flat buffers)."""
