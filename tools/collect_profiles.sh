@@ -1,0 +1,33 @@
+#!/bin/bash
+# Per-configuration profiles of bench.py on the GPU box (one MI355X): for every single-GPU configuration of the
+# headline benchmark a plain run (JSON line), a rocprofv3 kernel trace (reduced to the timed steps by
+# tools/prof_summary.py) and, for the training step and the ViTPose-H inference, the two HBM-traffic counter passes.
+# usage: tools/collect_profiles.sh <out-dir> <tag>      (run through gpurun; every GPU step has its own time limit)
+set -e
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r02}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+run() {   # name, steps, warmup, bench args...
+    local name=$1 steps=$2 warm=$3; shift 3
+    timeout -k 10 240 python3 bench.py --steps "$steps" --warmup "$warm" "$@" > "$OUT/${TAG}_${name}_bench.json" 2> "$OUT/${name}.err"
+    timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$name" -o t -- python3 bench.py --steps "$steps" --warmup "$warm" --no-cpu-baseline "$@" > "$OUT/trace_$name.log" 2>&1
+    python3 tools/prof_summary.py "$OUT/trace_$name/t_results.db" --steps "$steps" --all $((steps + warm + 1)) --csv "$OUT/${TAG}_${name}_kernel_stats.csv" > "$OUT/${TAG}_${name}_summary.txt"
+    rm -rf "$OUT/trace_$name"
+    echo "== $name"; head -3 "$OUT/${TAG}_${name}_summary.txt"
+}
+pmc() {   # name, bench args...
+    local name=$1; shift
+    for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${name}_$c" -o pmc -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline "$@" > "$OUT/pmc_${name}_$c.log" 2>&1
+    done
+    python3 tools/pmc_traffic.py "$OUT/pmc_${name}_FETCH_SIZE/pmc_counter_collection.csv" "$OUT/pmc_${name}_WRITE_SIZE/pmc_counter_collection.csv" "$OUT/${TAG}_${name}_pmc_traffic.json"
+    rm -rf "$OUT/pmc_${name}_FETCH_SIZE" "$OUT/pmc_${name}_WRITE_SIZE"
+    echo "== pmc $name done"
+}
+run train_B 20 5
+run infer_B64 30 5 --mode infer --model B --batch 64
+run train_L32 10 4 --model L --batch 32
+run infer_H128 10 4 --mode infer --model H --batch 128
+run infer_B64_exact 20 5 --mode infer --model B --batch 64 --exact
+pmc train_B
+pmc infer_H128 --mode infer --model H --batch 128
