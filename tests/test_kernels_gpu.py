@@ -779,6 +779,51 @@ def test_gemm_w2_epilogues(dev):
                              tile_mode=4))
 
 
+# ------------------------------------------------------------------ persistent 192 x 192 tiles (tile_mode 5)
+@pytest.mark.parametrize('M,N,K', [(7680, 1536, 768), (12288, 3072, 768), (1920, 1000, 640), (3840, 4096, 1024),
+                                   (192, 192, 640)])
+def test_gemm_persistent_matches_one_tile_per_workgroup(dev, M, N, K):
+    """The persistent kernel (a workgroup walks several output tiles and writes tile i under the K loop of tile
+    i + 1) accumulates and rounds exactly as the one-tile-per-workgroup kernel of the same tile shape does: the
+    outputs are bit-identical for every epilogue it supports, with one round of tiles or several, ragged N included."""
+    from vitpose_amd import _lib
+    X, Y = rnd((M, K), dev, 3).bfloat16(), rnd((N, K), dev, 4, 0.1).bfloat16()
+    bias = rnd((N,), dev, 5)
+    outs = {}
+    for mode in (3, 5):
+        o = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+        run(lambda p: p.gemm(X, Y, o, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, epilogue=_lib.VP_EPI_BF16, tile_mode=mode))
+        g, u = torch.full_like(o, float('nan')), torch.full_like(o, float('nan'))
+        run(lambda p: p.gemm(X, Y, g, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, out2=u, epilogue=_lib.VP_EPI_GELU,
+                             tile_mode=mode))
+        g1 = torch.full_like(o, float('nan'))      # inference: no pre-activation copy
+        run(lambda p: p.gemm(X, Y, g1, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, epilogue=_lib.VP_EPI_GELU, tile_mode=mode))
+        Yt = Y.t().contiguous()                     # [K][N]: the data-gradient layout
+        aux = rnd((M, N), dev, 9).bfloat16()
+        d = torch.full_like(o, float('nan'))
+        run(lambda p: p.gemm(X, Yt, d, M, N, K, ldx=K, ldy=N, ldo=N, y_kmajor=True, epilogue=_lib.VP_EPI_DGELU, aux=aux,
+                             ldaux=N, tile_mode=mode))
+        outs[mode] = (o, g, u, g1, d)
+    for a, b, name in zip(outs[3], outs[5], ('bias', 'gelu', 'pre-activation', 'gelu without copy', 'dgelu')):
+        assert not torch.isnan(b.float()).any(), name
+        assert torch.equal(a, b), name
+    acc = X.float() @ Y.float().t() + bias
+    torch.testing.assert_close(outs[5][0].float(), acc, rtol=1e-2, atol=1e-2)
+
+
+def test_gemm_persistent_refuses_what_it_does_not_cover(dev):
+    from vitpose_amd import _lib
+    M, N, K = 384, 384, 256       # fewer than 9 K tiles
+    X, Y = rnd((M, K), dev, 3).bfloat16(), rnd((N, K), dev, 4, 0.1).bfloat16()
+    o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(Exception):
+        run(lambda p: p.gemm(X, Y, o, M, N, K, ldx=K, ldy=K, ldo=N, epilogue=_lib.VP_EPI_BF16, tile_mode=5))
+    o32 = torch.empty(M, N, device=dev)
+    X2, Y2 = rnd((M, 768), dev, 3).bfloat16(), rnd((N, 768), dev, 4, 0.1).bfloat16()
+    with pytest.raises(Exception):                 # f32 outputs are outside this schedule
+        run(lambda p: p.gemm(X2, Y2, o32, M, N, 768, ldx=768, ldy=768, ldo=N, epilogue=_lib.VP_EPI_F32, tile_mode=5))
+
+
 @pytest.mark.parametrize('Ci,Co', [(64, 64), (768, 256), (40, 72)])
 def test_deconv_weight_prep_layouts(dev, Ci, Co):
     wt = rnd((Ci, Co, 4, 4), dev, 1)

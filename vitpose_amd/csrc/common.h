@@ -44,6 +44,42 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* lds_ptr) {
         (bf16x4 __attribute__((address_space(3)))*)(lds_ptr));
 }
 
+// The same read issued as inline assembly, for kernels that fill LDS by LDS-DMA (global_load ... lds).  The
+// compiler cannot prove that the builtin's read does not alias the LDS-DMA writes in flight, so it puts
+// `s_waitcnt vmcnt(0)` in front of it: every outstanding prefetch -- including the ones issued a moment ago for a
+// K tile two steps ahead -- has to land before the read issues, which removes the prefetch distance a multi-stage K
+// loop is built around (those kernels order LDS-DMA against reads with their own counted waits + barriers).  The
+// compiler does not see this read at all: it inserts no wait for its RESULT either, so every consumer must come
+// after lds_fence() on the registers it reads.
+// (`off`: a byte offset that is a compile-time constant after inlining; it travels in the instruction's offset field,
+// so reads that differ only in it share one address register)
+__device__ __forceinline__ bf16x4 lds_read_tr_raw(const char* lds_ptr, int off) {
+#ifdef VP_TR_BUILTIN   /* A/B build: the builtin read and the compiler's own waits */
+    return lds_read_tr(lds_ptr + off);
+#else
+    bf16x4 r;
+    const unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(off) : "memory");
+    return r;
+#endif
+}
+// Wait for every LDS read of this wave (lgkmcnt(0)); the registers passed in are tied to the wait, so that no
+// instruction that reads them can be scheduled before it.
+template <int N_>
+__device__ __forceinline__ void lds_fence(bf16x8 (&f)[N_]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N_; ++i) asm volatile("" : "+v"(f[i]));
+}
+template <int N_, int S_>
+__device__ __forceinline__ void lds_fence(bf16x8 (&f)[N_][S_]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N_; ++i)
+#pragma unroll
+        for (int j = 0; j < S_; ++j) asm volatile("" : "+v"(f[i][j]));
+}
+
 // erf(z) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution): one
 // v_rcp, one v_exp and a 5-term Horner chain instead of the ~40-instruction libm erff, which made
 // the GELU epilogues VALU-bound.  *e_out receives exp(-z^2) (shared with the Gaussian pdf).

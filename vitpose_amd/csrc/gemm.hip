@@ -78,10 +78,12 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int s, i
         const int r = rbase + li;
         return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((((s << 2) + g) ^ (r & 7)) << 4));
     } else {
-        const int q = li >> 2, p = li & 3, unit = rbase >> 4;
-        const int kr0 = 32 * s + 8 * g + q, kr1 = kr0 + 4;
-        bf16x4 lo = lds_read_tr(lds + kr0 * 256 + ((unit ^ kmaj_key(kr0)) << 5) + (p << 3));
-        bf16x4 hi = lds_read_tr(lds + kr1 * 256 + ((unit ^ kmaj_key(kr1)) << 5) + (p << 3));
+        // k rows 32 s + 8 g + q and 4 below: the swizzle key depends on the lane part (8 g + q) only, so both rows of
+        // both sub-steps read at constant offsets from one per-lane address
+        const int q = li >> 2, p = li & 3, unit = rbase >> 4, kq = 8 * g + q;
+        const char* base = lds + kq * 256 + ((unit ^ kmaj_key(kq)) << 5) + (p << 3);
+        bf16x4 lo = lds_read_tr_raw(base, s * 8192);
+        bf16x4 hi = lds_read_tr_raw(base, s * 8192 + 1024);
         return cat8(lo, hi);
     }
 }
@@ -447,6 +449,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(Operand X, Operand Y,
                 for (int a = 0; a < 4; ++a) xf[a] = read_frag<XKMAJ>(lx, wm * 64 + a * 16, s, lane);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) yf[b] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
+                if constexpr (XKMAJ) lds_fence(xf);
+                if constexpr (YKMAJ) lds_fence(yf);
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand
             for (int b = 0; b < 4; ++b) yf[b] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
 #pragma unroll
             for (int a = 0; a < 6; ++a) xf[a] = read_frag<false>(lx, wm * 96 + a * 16, s, lane);
+            if constexpr (YKMAJ) lds_fence(yf);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -935,6 +940,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
             }
             stage(3, u + 1);
             __builtin_amdgcn_s_barrier();
+            if constexpr (YKMAJ) lds_fence(y0);
+            if constexpr (XKMAJ) lds_fence(xf);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
@@ -963,6 +970,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
                 for (int b = 0; b < 2; ++b) y1[b][s] = read_frag<YKMAJ>(ly, ycol + 32 + b * 16, s, lane);
             stage(0, u + 1);
             __builtin_amdgcn_s_barrier();
+            if constexpr (YKMAJ) lds_fence(y1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
@@ -981,6 +989,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
                 for (int a = 0; a < 4; ++a) xf[a][s] = read_frag<XKMAJ>(lx, 64 + a * 16, s, lane);
             stage(1, u + 1);
             __builtin_amdgcn_s_barrier();
+            if constexpr (XKMAJ) lds_fence(xf);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
@@ -1117,15 +1126,15 @@ __device__ __forceinline__ void stage_unit_routed(const Operand& op, int r0, int
 // fragment `f` (16 rows / columns) of a 192-wide operand tile made of three 64-wide units
 template <bool KMAJ>
 __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s, int lane) {
-    const char* unit = op_units + (f >> 2) * UNIT_BYTES;
     const int rbase = (f & 3) * 16;
     if constexpr (!KMAJ) {
-        return read_frag<false>(unit, rbase, s, lane);
+        return read_frag<false>(op_units + (f >> 2) * UNIT_BYTES, rbase, s, lane);
     } else {
-        const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, u16 = rbase >> 4;
-        const int kr0 = 32 * s + 8 * g + q, kr1 = kr0 + 4;
-        bf16x4 lo = lds_read_tr(unit + kr0 * 128 + ((u16 ^ kmaj64_key(kr0)) << 5) + (p << 3));
-        bf16x4 hi = lds_read_tr(unit + kr1 * 128 + ((u16 ^ kmaj64_key(kr1)) << 5) + (p << 3));
+        // (as in read_frag<true>: one per-lane address per 16-column unit, everything else in the offset field)
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, u16 = rbase >> 4, kq = 8 * g + q;
+        const char* base = op_units + (f >> 2) * UNIT_BYTES + kq * 128 + ((u16 ^ kmaj64_key(kq)) << 5) + (p << 3);
+        bf16x4 lo = lds_read_tr_raw(base, s * 4096);
+        bf16x4 hi = lds_read_tr_raw(base, s * 4096 + 512);
         return cat8(lo, hi);
     }
 }
@@ -1267,6 +1276,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             stage(1, u + 2, nxt2);
             stage(3, u + 2, nxt2);
             __builtin_amdgcn_s_barrier();
+            if constexpr (YKMAJ) lds_fence(yf);
+            if constexpr (XKMAJ) lds_fence(xf);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
@@ -1298,6 +1309,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             stage(5, u + 2, nxt2);
             VP_WAIT_VM(6);
             __builtin_amdgcn_s_barrier();
+            if constexpr (XKMAJ) lds_fence(xf);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < (SPLIT3 ? 3 : 2); ++t)
@@ -1349,6 +1361,265 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice, pre);
     else
         run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice);
+}
+
+
+// =====================================================================================
+// Persistent 192 x 192 x 64 kernel: the epilogue of tile i runs under the K loop of tile i + 1
+// =====================================================================================
+// One workgroup per CU walks a list of output tiles (tile = slot, slot + grid, ...) through ONE continuous K-tile
+// pipeline: the LDS-DMA loads issued during the last two K tiles of an output tile already fetch the first two K tiles
+// of the next one, so only the first tile of a workgroup pays the pipeline fill.  When an output tile is complete its
+// accumulators move to a second register set (`pacc`) and the next K loop starts at once; the pending tile is written
+// fragment by fragment (16 x 16 per wave: the epilogue arithmetic + one 8-byte store per lane) in the first 18 phases of
+// K tiles 1-9 of that K loop, in the half of each phase where this wave reads LDS and the partner wave of its SIMD
+// streams MFMAs: the epilogue's VALU work issues in the shadow of those MFMAs and its HBM traffic shares the memory
+// system with operand loads instead of arriving from every CU at once.  The last tile of a workgroup is written the
+// ordinary way.
+// Counted waits: loads return in order, so "all LDS-DMA loads of the previous window have landed" = at most (6 + the
+// global LOADS issued since) operations outstanding; the stores in between only make that wait stricter.  The bias /
+// pre-activation loads of the pending tile are issued at the tile switch or six fragments ahead, and always have a
+// counted wait of the K loop between them and their use.
+// Needs K >= 10 * 64 (one fragment per phase, 18 fragments, after one K tile without).  bf16 outputs (VP_EPI_BF16 / GELU / DGELU), no row remap,
+// no column scale.
+template <int N_>
+using ic = std::integral_constant<int, N_>;
+
+template <int N_>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+// Global loads the compiler does not track (it would otherwise wait for EVERY outstanding vector-memory operation,
+// the LDS-DMA prefetches included, in front of their first use inside the K loop): the caller guarantees that a
+// counted wait lies between the load and loaded(), which ties the register to that point of the program.
+__device__ __forceinline__ void gload_raw(bf16x4& dst, const void* p) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload_raw(f32x4& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void loaded(T& v) {
+    asm volatile("" : "+v"(v));
+}
+
+template <bool XKMAJ, bool YKMAJ, int EPI>
+__global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Operand Y, int M, int N, int K,
+                                                                 int tiles_n, int ntiles, Epi e) {
+    static_assert(EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_DGELU, "bf16 outputs only");
+    __shared__ __attribute__((aligned(16))) char lds[3][STAGE3_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+    const int G = gridDim.x;
+    const int tiles_m = ntiles / tiles_n;
+    const int nk = K / BK;
+    auto coords = [&](int t, int& i0, int& j0) {
+        const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
+        const int gm = min(tiles_m - gid * 8, 8);
+        i0 = (gid * 8 + tin % gm) * T3;
+        j0 = (tin / gm) * T3;
+    };
+    int t = xcd_remap(blockIdx.x, G);          // G <= ntiles: every workgroup owns at least one tile
+    int i0, j0;
+    coords(t, i0, j0);
+
+    f32x4 acc[6][3], pacc[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = pacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool pending = false;
+    int pi0 = 0, pj0 = 0;
+    // per pending tile: this lane's first output element, bias of its 12 columns, pre-activation prefetch ring
+    bf16* po = nullptr;
+    bf16* po2 = nullptr;
+    const bf16* paux = nullptr;
+    bool pcol_ok[3];
+    int pcoff[3];                    // column offset of fragment b for loads (clamped into the row)
+    f32x4 pbias[3];
+    bf16x4 uq[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) uq[i] = bf16x4{};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { pcol_ok[b] = false; pcoff[b] = 0; pbias[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto stage_at = [&](int unit, int si0, int sj0, int sk, int st) {
+        char* dst = lds[st] + unit * UNIT_BYTES;
+        if (unit < 3) stage_unit<XKMAJ>(X, si0 + unit * 64, sk, dst, wave, lane);
+        else stage_unit<YKMAJ>(Y, sj0 + (unit - 3) * 64, sk, dst, wave, lane);
+    };
+    auto load_u = [&](bf16x4& dst, int f) {       // pre-activations of fragment f = (a, b) of the pending tile
+        const int a = f / 3, b = f - a * 3;
+        gload_raw(dst, paux + (size_t)(a * 16) * e.ldaux + pcoff[b]);
+    };
+    // epilogue of fragment F of the pending tile (F < 0: nothing)
+    auto slot = [&](auto ftag) {
+        constexpr int F = decltype(ftag)::value;
+        if constexpr (F >= 0) {
+            constexpr int a = F / 3, b = F % 3;
+            const bool ok = pcol_ok[b];
+            f32x4 v = pacc[a][b];
+            bf16* o = po + (size_t)(a * 16) * e.ldo + b * 16;
+            if constexpr (EPI == VP_EPI_DGELU) {
+                loaded(uq[F % 6]);
+                const bf16x4 u = uq[F % 6];
+                if constexpr (F + 6 < 18) load_u(uq[F % 6], F + 6);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+            } else {
+                if constexpr (a == 0) loaded(pbias[b]);
+                v = v + pbias[b];
+                if constexpr (EPI == VP_EPI_GELU) {
+                    if (po2 && VP_ST_OK(ok))
+                        *reinterpret_cast<bf16x4*>(po2 + (size_t)(a * 16) * e.ldo + b * 16) = pack4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+            }
+            if (VP_ST_OK(ok)) *reinterpret_cast<bf16x4*>(o) = pack4(v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    // pipeline fill: K tiles 0 and 1 of the first output tile
+#pragma unroll
+    for (int un = 0; un < 6; ++un) stage_at(un, i0, j0, 0, 0);
+#pragma unroll
+    for (int un = 0; un < 6; ++un) stage_at(un, i0, j0, BK, 1);
+    VP_WAIT_VM(6);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
+
+    int cur = 0, nxt2 = 2;                        // stage of K tile u, of K tile u + 2
+    while (true) {
+        const int tn = t + G;
+        const bool has_next = tn < ntiles;
+        int ni0 = i0, nj0 = j0;
+        if (has_next) coords(tn, ni0, nj0);
+        int u = 0;
+        // one K tile; S0 / S1 = pending-tile fragments written in its two phases
+        auto iter = [&](auto s0tag, auto s1tag) {
+            constexpr int S0 = decltype(s0tag)::value, S1 = decltype(s1tag)::value;
+            constexpr int NLOADS = EPI == VP_EPI_DGELU ? (S0 >= 0 && S0 + 6 < 18) + (S1 >= 0 && S1 + 6 < 18) : 0;
+            int si0 = i0, sj0 = j0, sk = (u + 2) * BK;        // K tile u + 2, possibly of the next output tile
+            if (u + 2 >= nk) {
+                if (has_next) { si0 = ni0; sj0 = nj0; sk = (u + 2 - nk) * BK; }
+                else sk = (nk - 1) * BK;
+            }
+            const char* lx = lds[cur];
+            const char* ly = lds[cur] + 3 * UNIT_BYTES;
+            bf16x8 xf[3][2], yf[3][2];
+            // ---- phase 0: rows 0-47 of the wave's block
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) yf[b][s] = read_frag3<YKMAJ>(ly, 3 * wc + b, s, lane);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) xf[a][s] = read_frag3<XKMAJ>(lx, 6 * grp + a, s, lane);
+            }
+            stage_at(0, si0, sj0, sk, nxt2);
+            stage_at(1, si0, sj0, sk, nxt2);
+            stage_at(3, si0, sj0, sk, nxt2);
+            slot(s0tag);
+            __builtin_amdgcn_s_barrier();
+            if constexpr (YKMAJ) lds_fence(yf);
+            if constexpr (XKMAJ) lds_fence(xf);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1: rows 48-95
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) xf[a][s] = read_frag3<XKMAJ>(lx, 6 * grp + 3 + a, s, lane);
+            stage_at(2, si0, sj0, sk, nxt2);
+            stage_at(4, si0, sj0, sk, nxt2);
+            stage_at(5, si0, sj0, sk, nxt2);
+            slot(s1tag);
+            wait_vm<6 + NLOADS>();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (XKMAJ) lds_fence(xf);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        acc[3 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[3 + a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+            ++u;
+        };
+        if (pending) {
+            iter(ic<-1>{}, ic<-1>{});      // the loads issued at the tile switch land behind this K tile's wait
+            iter(ic<0>{}, ic<1>{});
+            iter(ic<2>{}, ic<3>{});
+            iter(ic<4>{}, ic<5>{});
+            iter(ic<6>{}, ic<7>{});
+            iter(ic<8>{}, ic<9>{});
+            iter(ic<10>{}, ic<11>{});
+            iter(ic<12>{}, ic<13>{});
+            iter(ic<14>{}, ic<15>{});
+            iter(ic<16>{}, ic<17>{});
+        }
+#pragma unroll 1
+        while (u < nk) iter(ic<-1>{}, ic<-1>{});
+        // the tile is complete: it becomes the pending one
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                pacc[a][b] = acc[a][b];
+                acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        pending = true;
+        pi0 = i0;
+        pj0 = j0;
+        if (!has_next) break;
+        {
+            // M is a multiple of the tile height (checked by the launcher): every row exists.  Column fragments past
+            // N are not stored; their loads read a clamped, in-bounds address and the values are dropped.
+            const int row = pi0 + grp * 96 + li, col = pj0 + wc * 48 + g * 4;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                pcol_ok[b] = col + b * 16 + 3 < N;
+                pcoff[b] = min(col + b * 16, N - 4) - col;
+            }
+            po = (bf16*)e.out + (size_t)row * e.ldo + col;
+            if constexpr (EPI == VP_EPI_GELU) po2 = e.out2 ? (bf16*)e.out2 + (size_t)row * e.ldo + col : nullptr;
+            if constexpr (EPI == VP_EPI_DGELU) {
+                paux = (const bf16*)e.aux + (size_t)row * e.ldaux + col;
+#pragma unroll
+                for (int f = 0; f < 6; ++f) load_u(uq[f], f);
+            } else if (e.bias) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) gload_raw(pbias[b], e.bias + col + pcoff[b]);
+            }
+        }
+        t = tn;
+        i0 = ni0;
+        j0 = nj0;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // match group 1's extra barrier
+    VP_WAIT_VM(0);                                 // no LDS-DMA may outlive the workgroup
+    if (((N | e.ldo) & 7) == 0) {
+        __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free for staging
+        run_epilogue_staged<EPI, 6, 3, 3>(e, pacc, pi0 + grp * 96, pj0 + wc * 48, lane, M, N,
+                                          &lds[0][0] + wave * (48 * 112));
+    } else {
+        run_epilogue<EPI, 6, 3>(e, pacc, pi0 + grp * 96, pj0 + wc * 48, lane, M, N);
+    }
 }
 
 inline int num_cus() {
@@ -1460,6 +1731,30 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
                     return VP_ERR_UNSUPPORTED;
             }
 #undef VP_GEMMR_CASE
+        }
+        VP_LAUNCH_RET();
+    }
+    if (a->tile_mode == 5) {
+        // persistent 192-tile kernel (epilogue of tile i under the K loop of tile i + 1): forward / data-gradient
+        // products with a bf16 output, more than one round of tiles, at least 9 K tiles
+        const int tm5 = (a->M + T3 - 1) / T3, tn5 = (a->N + T3 - 1) / T3, nt5 = tm5 * tn5;
+        if (XK || split > 1 || nk < 10 || a->out_row_div > 0 || a->colscale || a->M % T3 != 0 || a->N < 4)
+            return VP_ERR_UNSUPPORTED;
+        const int grid5 = nt5 < num_cus() ? nt5 : num_cus();
+        if constexpr (!XK) {
+#define VP_GEMM5_CASE(EPI)                                                                                    \
+    case EPI:                                                                                                 \
+        hipLaunchKernelGGL((gemm192p_kernel<false, YK, EPI>), dim3(grid5), dim3(T2_THREADS), 0, st, X, Y, a->M, \
+                           a->N, a->K, tn5, nt5, e);                                                          \
+        break;
+            switch (a->epilogue) {
+                VP_GEMM5_CASE(VP_EPI_BF16)
+                VP_GEMM5_CASE(VP_EPI_GELU)
+                VP_GEMM5_CASE(VP_EPI_DGELU)
+                default:
+                    return VP_ERR_UNSUPPORTED;
+            }
+#undef VP_GEMM5_CASE
         }
         VP_LAUNCH_RET();
     }
