@@ -83,7 +83,10 @@ typedef struct vp_gemm_args {
     int tail_force;              /* 1: always split the tail round when tail_ws is given (default: heuristic) */
     int tile_mode;               /* 0: choose by shape; 1: 128x128 tiles (2 workgroups / CU); 2: 256x256 tiles (1 / CU);
                                     3: 192x192 tiles (1 / CU, three LDS stages); 4: 192x128 tiles, 2 workgroups / CU
-                                    (k-contiguous x, no K split: VP_ERR_UNSUPPORTED otherwise) */
+                                    (k-contiguous x, no K split: VP_ERR_UNSUPPORTED otherwise); 5: 192x192 tiles, one
+                                    persistent workgroup per CU that writes output tile i while it accumulates tile i + 1
+                                    (k-contiguous x, bf16 outputs VP_EPI_BF16 / GELU / DGELU, K >= 640, M % 192 == 0,
+                                    no K split / row remap / colscale: VP_ERR_UNSUPPORTED otherwise) */
     /* optional per-image routing of the Y operand: the mixture-of-experts FFN of ViTPose+ (MoEMlp.forward,
      * mmpose/models/backbones/vit_moe.py:98-115: the last `part_features` output channels of fc2 come from the
      * expert Linear selected by the image's dataset index).  Rows are images of exactly 192 tokens (M % 192 == 0);

@@ -91,14 +91,14 @@ def test_routed_gemm_exact(dev, E, P, Hd, nexp):
     # data gradient: dX[i][k] = sum_j dY[i][j] W_eff(image of i)[j][k]
     dY = ints((M, E), dev, seed=5)
     dx = torch.full((M, Hd), float('nan'), device=dev, dtype=torch.bfloat16)
-    ones = torch.zeros(M, Hd, device=dev, dtype=torch.bfloat16)     # gelu'(0) = 0.5: exact halves
+    ones = torch.zeros(M, Hd, device=dev, dtype=torch.bfloat16)     # gelu'(0) = 0.5 (to the 8e-6 of the epilogue's polynomial)
     run(lambda p: p.gemm(dY.bfloat16(), half, dx, M, Hd, E, ldx=E, ldy=Hd, ldo=Hd, y_kmajor=True,
                          epilogue=_lib.VP_EPI_DGELU, aux=ones, ldaux=Hd, route=(expert, delta, None, Ns)))
     ref = torch.empty(M, Hd, device=dev)
     for b in range(B):
         W = torch.cat([Wsh, We[int(expert[b])]])
         ref[b * T:(b + 1) * T] = dY[b * T:(b + 1) * T] @ W
-    assert torch.equal(dx.float(), (0.5 * ref).bfloat16().float())
+    torch.testing.assert_close(dx.float(), 0.5 * ref, rtol=2.0 ** -7, atol=0.26)   # bf16 rounding of integer halves
 
 
 def test_grouped_wgrad_kmap_exact(dev):

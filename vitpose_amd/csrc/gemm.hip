@@ -185,8 +185,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
                 const bool ok = rok && cok[b];
                 if constexpr (EPI == VP_EPI_GELU) {
                     if (o2 && VP_ST_OK(ok)) *reinterpret_cast<bf16x4*>(o2 + col[b]) = pack4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    v = gelu_erf(v);
                 }
                 if constexpr (EPI == VP_EPI_SCALE_RELU) {
 #pragma unroll
@@ -241,10 +240,11 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
                 f32x4 v = acc[a][b];
+                if constexpr (EPI == VP_EPI_DGELU) {
+                    v *= gelu_erf_grad(__builtin_convertvector(u[b], f32x4));
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (EPI == VP_EPI_DGELU) v[r] *= gelu_erf_grad((float)u[b][r]);
-                    else v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
+                    for (int r = 0; r < 4; ++r) v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
                 }
                 if (VP_ST_OK(rok && cok[b])) *reinterpret_cast<bf16x4*>(o + col[b]) = pack4(v[0], v[1], v[2], v[3]);
             }
@@ -319,16 +319,16 @@ __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[F
                     f32x4 v;
                     if constexpr (EPI == VP_EPI_DGELU || EPI == VP_EPI_DRELU) {
                         v = acc[A][b];
+                        if constexpr (EPI == VP_EPI_DGELU) {
+                            v *= gelu_erf_grad(__builtin_convertvector(u[b], f32x4));
+                        } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if constexpr (EPI == VP_EPI_DGELU) v[r] *= gelu_erf_grad((float)u[b][r]);
-                            else v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
+                            for (int r = 0; r < 4; ++r) v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
                         }
                     } else {
                         v = acc[A][b] * cs[b] + bias[b];
                         if (EPI == VP_EPI_GELU && pass == 1) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                            v = gelu_erf(v);
                         }
                         if constexpr (EPI == VP_EPI_SCALE_RELU) {
 #pragma unroll
@@ -1436,14 +1436,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
     bf16* po = nullptr;
     bf16* po2 = nullptr;
     const bf16* paux = nullptr;
-    bool pcol_ok[3];
-    int pcoff[3];                    // column offset of fragment b for loads (clamped into the row)
     f32x4 pbias[3];
     bf16x4 uq[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) uq[i] = bf16x4{};
 #pragma unroll
-    for (int b = 0; b < 3; ++b) { pcol_ok[b] = false; pcoff[b] = 0; pbias[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int b = 0; b < 3; ++b) pbias[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool two_outputs = EPI == VP_EPI_GELU && e.out2 != nullptr;
 
     auto stage_at = [&](int unit, int si0, int sj0, int sk, int st) {
         char* dst = lds[st] + unit * UNIT_BYTES;
@@ -1452,33 +1451,32 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
     };
     auto load_u = [&](bf16x4& dst, int f) {       // pre-activations of fragment f = (a, b) of the pending tile
         const int a = f / 3, b = f - a * 3;
-        gload_raw(dst, paux + (size_t)(a * 16) * e.ldaux + pcoff[b]);
+        gload_raw(dst, paux + (size_t)(a * 16) * e.ldaux + b * 16);
     };
-    // epilogue of fragment F of the pending tile (F < 0: nothing)
+    // Epilogue of fragment F of the pending tile (F < 0: nothing).  Only tiles that lie wholly inside the output are
+    // deferred, so every store below is unconditional: the number of vector-memory operations a slot issues is a
+    // compile-time constant (the counted waits of the K loop rely on it).
     auto slot = [&](auto ftag) {
         constexpr int F = decltype(ftag)::value;
         if constexpr (F >= 0) {
             constexpr int a = F / 3, b = F % 3;
-            const bool ok = pcol_ok[b];
             f32x4 v = pacc[a][b];
             bf16* o = po + (size_t)(a * 16) * e.ldo + b * 16;
             if constexpr (EPI == VP_EPI_DGELU) {
                 loaded(uq[F % 6]);
                 const bf16x4 u = uq[F % 6];
                 if constexpr (F + 6 < 18) load_u(uq[F % 6], F + 6);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+                v *= gelu_erf_grad(__builtin_convertvector(u, f32x4));
             } else {
                 if constexpr (a == 0) loaded(pbias[b]);
                 v = v + pbias[b];
                 if constexpr (EPI == VP_EPI_GELU) {
-                    if (po2 && VP_ST_OK(ok))
+                    if (two_outputs)
                         *reinterpret_cast<bf16x4*>(po2 + (size_t)(a * 16) * e.ldo + b * 16) = pack4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    v = gelu_erf(v);
                 }
             }
-            if (VP_ST_OK(ok)) *reinterpret_cast<bf16x4*>(o) = pack4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<bf16x4*>(o) = pack4(v[0], v[1], v[2], v[3]);
         }
     };
 
@@ -1498,9 +1496,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
         int ni0 = i0, nj0 = j0;
         if (has_next) coords(tn, ni0, nj0);
         int u = 0;
-        // one K tile; S0 / S1 = pending-tile fragments written in its two phases
+        // One K tile; S0 / S1 = pending-tile fragments written in its two phases.  Vector-memory operations between
+        // two counted waits, in issue order: 3 LDS-DMA, slot S0, slot S1, 3 LDS-DMA -- everything older (the LDS-DMA
+        // loads of K tile u + 1 among it) has landed once at most that many operations are outstanding (loads and
+        // stores of a wave complete in issue order on this target).
         auto iter = [&](auto s0tag, auto s1tag) {
             constexpr int S0 = decltype(s0tag)::value, S1 = decltype(s1tag)::value;
+            constexpr int NSLOT = (S0 >= 0) + (S1 >= 0);
             constexpr int NLOADS = EPI == VP_EPI_DGELU ? (S0 >= 0 && S0 + 6 < 18) + (S1 >= 0 && S1 + 6 < 18) : 0;
             int si0 = i0, sj0 = j0, sk = (u + 2) * BK;        // K tile u + 2, possibly of the next output tile
             if (u + 2 >= nk) {
@@ -1540,11 +1542,12 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int a = 0; a < 3; ++a) xf[a][s] = read_frag3<XKMAJ>(lx, 6 * grp + 3 + a, s, lane);
+            slot(s1tag);
             stage_at(2, si0, sj0, sk, nxt2);
             stage_at(4, si0, sj0, sk, nxt2);
             stage_at(5, si0, sj0, sk, nxt2);
-            slot(s1tag);
-            wait_vm<6 + NLOADS>();
+            if (EPI == VP_EPI_GELU && two_outputs) wait_vm<6 + 2 * NSLOT>();
+            else wait_vm<6 + NSLOT + NLOADS>();
             __builtin_amdgcn_s_barrier();
             if constexpr (XKMAJ) lds_fence(xf);
             __builtin_amdgcn_s_setprio(1);
@@ -1575,36 +1578,37 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
         }
 #pragma unroll 1
         while (u < nk) iter(ic<-1>{}, ic<-1>{});
-        // the tile is complete: it becomes the pending one
+        // The tile is complete.  A tile that lies wholly inside the output becomes the pending one; a ragged last
+        // column tile is written at once with the guarded epilogue (registers -> global, no LDS: the stages hold the
+        // next tile's prefetch).
+        pending = j0 + T3 <= N;
+        if (pending) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) pacc[a][b] = acc[a][b];
+            pi0 = i0;
+            pj0 = j0;
+        } else {
+            run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N);
+        }
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                pacc[a][b] = acc[a][b];
-                acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        pending = true;
-        pi0 = i0;
-        pj0 = j0;
+            for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!has_next) break;
-        {
-            // M is a multiple of the tile height (checked by the launcher): every row exists.  Column fragments past
-            // N are not stored; their loads read a clamped, in-bounds address and the values are dropped.
+        if (pending) {
+            // M is a multiple of the tile height (checked by the launcher): every row exists
             const int row = pi0 + grp * 96 + li, col = pj0 + wc * 48 + g * 4;
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                pcol_ok[b] = col + b * 16 + 3 < N;
-                pcoff[b] = min(col + b * 16, N - 4) - col;
-            }
             po = (bf16*)e.out + (size_t)row * e.ldo + col;
-            if constexpr (EPI == VP_EPI_GELU) po2 = e.out2 ? (bf16*)e.out2 + (size_t)row * e.ldo + col : nullptr;
+            if constexpr (EPI == VP_EPI_GELU) po2 = two_outputs ? (bf16*)e.out2 + (size_t)row * e.ldo + col : nullptr;
             if constexpr (EPI == VP_EPI_DGELU) {
                 paux = (const bf16*)e.aux + (size_t)row * e.ldaux + col;
 #pragma unroll
                 for (int f = 0; f < 6; ++f) load_u(uq[f], f);
             } else if (e.bias) {
 #pragma unroll
-                for (int b = 0; b < 3; ++b) gload_raw(pbias[b], e.bias + col + pcoff[b]);
+                for (int b = 0; b < 3; ++b) gload_raw(pbias[b], e.bias + col + b * 16);
             }
         }
         t = tn;
@@ -1613,12 +1617,14 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // match group 1's extra barrier
     VP_WAIT_VM(0);                                 // no LDS-DMA may outlive the workgroup
-    if (((N | e.ldo) & 7) == 0) {
-        __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free for staging
-        run_epilogue_staged<EPI, 6, 3, 3>(e, pacc, pi0 + grp * 96, pj0 + wc * 48, lane, M, N,
-                                          &lds[0][0] + wave * (48 * 112));
-    } else {
-        run_epilogue<EPI, 6, 3>(e, pacc, pi0 + grp * 96, pj0 + wc * 48, lane, M, N);
+    if (pending) {
+        if (((N | e.ldo) & 7) == 0) {
+            __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free for staging
+            run_epilogue_staged<EPI, 6, 3, 3>(e, pacc, pi0 + grp * 96, pj0 + wc * 48, lane, M, N,
+                                              &lds[0][0] + wave * (48 * 112));
+        } else {
+            run_epilogue<EPI, 6, 3>(e, pacc, pi0 + grp * 96, pj0 + wc * 48, lane, M, N);
+        }
     }
 }
 

@@ -257,7 +257,12 @@ class Plan:
                         a.tile_mode = mode
                         return fn(ctypes.byref(a), s_)
                     return f
-                _TUNE_CACHE[key] = _pick_fastest({m: launch(m) for m in ((1, 2, 3) if x_kmajor else (1, 2, 3, 4))})
+                modes = [1, 2, 3] if x_kmajor else [1, 2, 3, 4]
+                if (not x_kmajor and not split3 and K >= 640 and M % 192 == 0 and row_map is None and colscale is None
+                        and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_GELU, _lib.VP_EPI_DGELU)
+                        and (M // 192) * ((N + 191) // 192) > 256):
+                    modes.append(5)       # persistent 192-tile kernel: only where a workgroup gets several tiles
+                _TUNE_CACHE[key] = _pick_fastest({m: launch(m) for m in modes})
             a.tile_mode = _TUNE_CACHE[key]
         self.tags[len(self.calls)] = (int(x_kmajor), int(y_kmajor), epilogue + (200 if split3 else 0), M, N,
                                       3 * K if split3 else K)
