@@ -674,21 +674,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_w2_kernel(Operand X, Operand
                     for (int b = 0; b < 4; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][t == 2], xf[a][t == 1], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-        } else
+        } else {
+            // the fragments of both 32-wide sub-steps are requested before the first MFMA: one LDS latency per K
+            // tile instead of two (two waves per SIMD leave 256 VGPRs per wave)
+            bf16x8 xf[6][2], yf[4][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 xf[6], yf[4];
+            for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) yf[b] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
+                for (int b = 0; b < 4; ++b) yf[b][s] = read_frag<YKMAJ>(ly, wn * 64 + b * 16, s, lane);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) xf[a] = read_frag<false>(lx, wm * 96 + a * 16, s, lane);
+                for (int a = 0; a < 6; ++a) xf[a][s] = read_frag<false>(lx, wm * 96 + a * 16, s, lane);
+            }
             if constexpr (YKMAJ) lds_fence(yf);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][s], xf[a][s], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
