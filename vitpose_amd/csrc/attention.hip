@@ -181,128 +181,148 @@ __global__ __launch_bounds__(256, (D & (D - 1)) == 0 ? 3 : 2) void attn_fwd_kern
     }
 }
 
-// Backward: recompute P from the forward's log-sum-exp.  Phase A (a wave owns 16
-// queries): S, dP -> dS -> dQ.  Phase B (a wave owns 16 keys): S^T, dP^T -> P^T, dS^T
-// -> dV, dK.  Every reduction is wave-local, and dq/dk/dv are written exactly once.
-// Phase A needs the K, V images (its Q / dO rows are MFMA fragments read straight from global
-// memory), phase B the Q, dO images (its K / V rows likewise): the two phases share ONE pair of
-// LDS images, which keeps a workgroup at ~50 KiB so three of them run per CU and
-// their load, compute and store phases overlap (the kernel is latency-, not MFMA-bound).
+// Backward: recompute P from the forward's log-sum-exp.  Phase A (a wave owns 16 queries): S, dP -> dS -> dQ.
+// Phase B (a wave owns 16 keys): S^T, dP^T -> P^T, dS^T -> dV, dK.  Every reduction is wave-local, and dq / dk / dv are
+// written exactly once.  One 768-thread workgroup per (image, head) keeps the K, V, Q and dO images in LDS together
+// (4 x 24 KiB at head_dim 64; one workgroup per CU), so every operand is read from memory ONCE, and runs both phases
+// at the same time: waves 0-5 own two 16-query tiles each (phase A), waves 6-11 two 16-key tiles each (phase B).  One
+// barrier in the whole kernel.  (A four-wave version with one PAIR of images that the two phases filled in turn --
+// three workgroups per CU, K / V / Q fetched twice and dO three times -- ran 2-4 % slower at every head_dim.)  The
+// kernel is bound by LDS fragment reads and exp2 latency, not by MFMA throughput or HBM.
 template <int D>
-__global__ __launch_bounds__(256, (D & (D - 1)) == 0 ? 3 : 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd,
-                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                          bf16* __restrict__ dqkv, int H, int E, float scale) {
+__global__ __launch_bounds__(768, 1) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd,
+                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16* __restrict__ dqkv, int H, int E, float scale) {
     using I = Img<D>;
-    __shared__ __attribute__((aligned(16))) char lds[2 * I::BYTES + 2 * NTOK * 4];
-    char* kimg = lds;                 // phase A: K, V
+    __shared__ __attribute__((aligned(16))) char lds[4 * I::BYTES + 2 * NTOK * 4];
+    char* kimg = lds;
     char* vimg = lds + I::BYTES;
-    char* qimg = lds;                 // phase B: Q, dO (same storage)
-    char* dimg = lds + I::BYTES;
-    float* s_lse = reinterpret_cast<float*>(lds + 2 * I::BYTES);
+    char* qimg = lds + 2 * I::BYTES;
+    char* dimg = lds + 3 * I::BYTES;
+    float* s_lse = reinterpret_cast<float*>(lds + 4 * I::BYTES);
     float* s_del = s_lse + NTOK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const size_t ld = 3 * (size_t)E;
     const bf16* base = qkv + (size_t)b * NTOK * ld + h * D;
     const bf16* dob = dout + (size_t)b * NTOK * E + h * D;
     const bf16* ofb = o_fwd + (size_t)b * NTOK * E + h * D;
-    I::fill(kimg, base + E, ld, tid);
-    I::fill(vimg, base + 2 * E, ld, tid);
     const float LOG2E = 1.44269504088896340736f;
-    if (tid < NTOK) {
+    // fill the four images (every 16-byte chunk of the (image, head) slice is fetched once)
+    {
+        constexpr int CH = D / 8, N4 = NTOK * CH;
+        for (int idx = tid; idx < N4; idx += 768) {
+            const int row = idx / CH, c = idx % CH;
+            const uint4 q = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c * 8);
+            const uint4 k = *reinterpret_cast<const uint4*>(base + E + (size_t)row * ld + c * 8);
+            const uint4 v = *reinterpret_cast<const uint4*>(base + 2 * E + (size_t)row * ld + c * 8);
+            const uint4 d = *reinterpret_cast<const uint4*>(dob + (size_t)row * E + c * 8);
+            const int off = I::off16(row, c);
+            *reinterpret_cast<uint4*>(qimg + off) = q;
+            *reinterpret_cast<uint4*>(kimg + off) = k;
+            *reinterpret_cast<uint4*>(vimg + off) = v;
+            *reinterpret_cast<uint4*>(dimg + off) = d;
+        }
+    }
+    // delta[q] = <dO[q], O[q]>: wave w takes rows 16 w .. 16 w + 15 as MFMA-layout fragments straight from memory
+    // (the dO rows are in flight for the image anyway: a cache hit), one partial dot per lane, summed over the 4 lane
+    // groups
+    {
+        const int row = wave * 16 + li;
+        const Frag<D> df = frag_global<D>(dob + (size_t)row * E, g);
+        const Frag<D> of = frag_global<D>(ofb + (size_t)row * E, g);
         float d = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < D / 8; ++ch) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(dob + (size_t)tid * E + 8 * ch);
-            const bf16x8 f = *reinterpret_cast<const bf16x8*>(ofb + (size_t)tid * E + 8 * ch);
+        for (int s = 0; s < Frag<D>::NS; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d += (float)a[j] * (float)f[j];
+            for (int j = 0; j < 8; ++j) d += (float)df.f[s][j] * (float)of.f[s][j];
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        if (g == 0) {
+            s_del[row] = d;
+            s_lse[row] = lse[(size_t)blockIdx.x * NTOK + row] * LOG2E;
         }
-        s_del[tid] = d;
-        s_lse[tid] = lse[(size_t)blockIdx.x * NTOK + tid] * LOG2E;
     }
     __syncthreads();
     const float c = scale * LOG2E;
     bf16* dq_base = dqkv + (size_t)b * NTOK * ld + h * D;
 
-    // ---------------- phase A: dQ ----------------
+    if (wave < 6) {
+        // ---------------- phase A: dQ of query tiles 2 wave, 2 wave + 1 ----------------
 #pragma unroll 1
-    for (int qt = 0; qt < 3; ++qt) {
-        const int q0 = wave * 48 + qt * 16;
-        const Frag<D> qf = frag_global<D>(base + (size_t)(q0 + li) * ld, g);
-        const Frag<D> df = frag_global<D>(dob + (size_t)(q0 + li) * E, g);
-        const float my_lse = s_lse[q0 + li], my_del = s_del[q0 + li];
-        f32x4 ds[12];
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q0 = (wave * 2 + qt) * 16;
+            const Frag<D> qf = I::frag(qimg, q0, lane);
+            const Frag<D> df = I::frag(dimg, q0, lane);
+            const float my_lse = s_lse[q0 + li], my_del = s_del[q0 + li];
+            f32x4 ds[12];
 #pragma unroll
-        for (int kt = 0; kt < 12; ++kt) {
-            const f32x4 sv = mfma_d<D>(I::frag(kimg, 16 * kt, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});
-            const f32x4 pv = mfma_d<D>(I::frag(vimg, 16 * kt, lane), df, f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int kt = 0; kt < 12; ++kt) {
+                const f32x4 sv = mfma_d<D>(I::frag(kimg, 16 * kt, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+                const f32x4 pv = mfma_d<D>(I::frag(vimg, 16 * kt, lane), df, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(sv[r] * c - my_lse) * (pv[r] - my_del);
-            // bound the scheduler's look-ahead: hoisting all 48 fragment reads would not fit 256 VGPRs
-            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4 o[D / 16];
+                for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(sv[r] * c - my_lse) * (pv[r] - my_del);
+                if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bounded look-ahead (register budget)
+            }
+            f32x4 o[D / 16];
 #pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < D / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            const bf16x8 sb = pack8(ds[2 * ks], ds[2 * ks + 1]);
+            for (int ks = 0; ks < 6; ++ks) {
+                const bf16x8 sb = pack8(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+                for (int dt = 0; dt < D / 16; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(kimg, ks, dt, lane), sb, o[dt], 0, 0, 0);
+            }
+            bf16* row = dq_base + (size_t)(q0 + li) * ld;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(kimg, ks, dt, lane), sb, o[dt], 0, 0, 0);
+                *reinterpret_cast<bf16x4*>(row + 16 * dt + 4 * g) =
+                    pack4(o[dt][0] * scale, o[dt][1] * scale, o[dt][2] * scale, o[dt][3] * scale);
         }
-        bf16* row = dq_base + (size_t)(q0 + li) * ld;
-#pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt)
-            *reinterpret_cast<bf16x4*>(row + 16 * dt + 4 * g) =
-                pack4(o[dt][0] * scale, o[dt][1] * scale, o[dt][2] * scale, o[dt][3] * scale);
-    }
-
-    // ---------------- phase B: dK, dV ----------------
-    __syncthreads();                  // every wave is done with the K, V images
-    I::fill(qimg, base, ld, tid);
-    I::fill(dimg, dob, (size_t)E, tid);
-    __syncthreads();
+    } else {
+        // ---------------- phase B: dK, dV of key tiles 2 (wave - 6), 2 (wave - 6) + 1 ----------------
 #pragma unroll 1
-    for (int kt = 0; kt < 3; ++kt) {
-        const int k0 = wave * 48 + kt * 16;
-        const Frag<D> kf = frag_global<D>(base + E + (size_t)(k0 + li) * ld, g);
-        const Frag<D> vf = frag_global<D>(base + 2 * E + (size_t)(k0 + li) * ld, g);
-        f32x4 dv[D / 16], dk[D / 16];
+        for (int kt = 0; kt < 2; ++kt) {
+            const int k0 = ((wave - 6) * 2 + kt) * 16;
+            const Frag<D> kf = I::frag(kimg, k0, lane);
+            const Frag<D> vf = I::frag(vimg, k0, lane);
+            f32x4 dv[D / 16], dk[D / 16];
 #pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < D / 16; ++dt) dv[dt] = dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int qs = 0; qs < 6; ++qs) {
-            f32x4 pp[2], dd[2];
+            for (int qs = 0; qs < 6; ++qs) {
+                f32x4 pp[2], dd[2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int qt = 2 * qs + hh;
-                const f32x4 sv = mfma_d<D>(I::frag(qimg, 16 * qt, lane), kf, f32x4{0.f, 0.f, 0.f, 0.f});
-                const f32x4 pv = mfma_d<D>(I::frag(dimg, 16 * qt, lane), vf, f32x4{0.f, 0.f, 0.f, 0.f});
-                // sv[r] = <q(16qt+4g+r), k(k0+li)>
-                const f32x4 ls = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
-                const f32x4 dl = *reinterpret_cast<const f32x4*>(s_del + 16 * qt + 4 * g);
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int qt = 2 * qs + hh;
+                    const f32x4 sv = mfma_d<D>(I::frag(qimg, 16 * qt, lane), kf, f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 pv = mfma_d<D>(I::frag(dimg, 16 * qt, lane), vf, f32x4{0.f, 0.f, 0.f, 0.f});
+                    // sv[r] = <q(16qt+4g+r), k(k0+li)>
+                    const f32x4 ls = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
+                    const f32x4 dl = *reinterpret_cast<const f32x4*>(s_del + 16 * qt + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pp[hh][r] = __builtin_amdgcn_exp2f(sv[r] * c - ls[r]);
-                    dd[hh][r] = pp[hh][r] * (pv[r] - dl[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        pp[hh][r] = __builtin_amdgcn_exp2f(sv[r] * c - ls[r]);
+                        dd[hh][r] = pp[hh][r] * (pv[r] - dl[r]);
+                    }
+                }
+                const bf16x8 pb = pack8(pp[0], pp[1]);
+                const bf16x8 sb = pack8(dd[0], dd[1]);
+#pragma unroll
+                for (int dt = 0; dt < D / 16; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(dimg, qs, dt, lane), pb, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(qimg, qs, dt, lane), sb, dk[dt], 0, 0, 0);
                 }
             }
-            const bf16x8 pb = pack8(pp[0], pp[1]);
-            const bf16x8 sb = pack8(dd[0], dd[1]);
+            bf16* row = dq_base + (size_t)(k0 + li) * ld;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(dimg, qs, dt, lane), pb, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(I::cols(qimg, qs, dt, lane), sb, dk[dt], 0, 0, 0);
+                *reinterpret_cast<bf16x4*>(row + E + 16 * dt + 4 * g) =
+                    pack4(dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale);
+                *reinterpret_cast<bf16x4*>(row + 2 * E + 16 * dt + 4 * g) = pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
             }
-        }
-        bf16* row = dq_base + (size_t)(k0 + li) * ld;
-#pragma unroll
-        for (int dt = 0; dt < D / 16; ++dt) {
-            *reinterpret_cast<bf16x4*>(row + E + 16 * dt + 4 * g) =
-                pack4(dk[dt][0] * scale, dk[dt][1] * scale, dk[dt][2] * scale, dk[dt][3] * scale);
-            *reinterpret_cast<bf16x4*>(row + 2 * E + 16 * dt + 4 * g) = pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
         }
     }
 }
@@ -482,7 +502,7 @@ extern "C" int vp_attention_bwd(const void* qkv, const void* out_fwd, const void
     VP_CHECK_ARG(qkv && out_fwd && dout && lse && dqkv && B > 0 && H > 0);
     if (tokens != NTOK) return VP_ERR_UNSUPPORTED;
     const int E = H * head_dim;
-    dim3 grid(B * H), block(256);
+    dim3 grid(B * H), block(768);
     switch (head_dim) {
         case 32: hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, 0, stream, (const bf16*)qkv, (const bf16*)out_fwd, (const bf16*)dout, lse, (bf16*)dqkv, H, E, scale); break;
         case 64: hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, 0, stream, (const bf16*)qkv, (const bf16*)out_fwd, (const bf16*)dout, lse, (bf16*)dqkv, H, E, scale); break;
