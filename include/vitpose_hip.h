@@ -215,6 +215,11 @@ int vp_bn_apply_relu(const void* z, void* a, const float* scale, const float* sh
 /* g = gradient wrt the BN output with the ReLU mask applied; dgamma/dbeta ACCUMULATE. */
 int vp_bn_bwd(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
               float* dgamma, float* dbeta, void* dz, int M, int C, vp_stream_t stream);
+/* The same with statistics that are constants of the backward pass (nn.BatchNorm2d in eval mode normalises with its
+ * running mean / variance, torch/nn/modules/batchnorm.py as used by topdown_heatmap_simple_head.py:333): mean / invstd =
+ * the running statistics (vp_bn_finalize with sums == NULL saves them), dz = g * gamma * invstd. */
+int vp_bn_bwd_eval(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+              float* dgamma, float* dbeta, void* dz, int M, int C, vp_stream_t stream);
 
 /* ------------------------------------------------------- simple decoder --------
  * TopdownHeatmapSimpleHead with upsample > 0 and/or final_conv_kernel = 3
@@ -413,6 +418,10 @@ int vp_drop_path_scales(float* dp, const float* rates, int depth, int per_block,
 /* x (bf16, n % 8 == 0) *= *scale_dev: seeds the backward pass with the incoming dL/dloss (autograd hands
  * TopDown.forward_train's loss a device scalar). */
 int vp_scale_bf16(void* x, size_t n, const float* scale_dev, vp_stream_t stream);
+/* Backward of `self.last_norm = nn.Identity()` (mmpose/models/backbones/vit.py:257, ViT(last_norm=False)): dx (f32
+ * [M][E]) = dy (bf16), dxb (bf16) = dy * rowscale[row / rows_per_scale] (the last Block's DropPath scale, or NULL). */
+int vp_identity_norm_bwd(const void* dy, const float* rowscale, int rows_per_scale, float* dx, void* dxb, int M, int E,
+                         vp_stream_t stream);
 /* hipMemsetAsync(p, 0, bytes) on `stream` (accumulating reductions start from zero). */
 int vp_zero(void* p, size_t bytes, vp_stream_t stream);
 /* Up to VP_ZERO_MAX_REGIONS small f32 regions zeroed by one launch (BatchNorm sums and parameter gradients, the

@@ -244,6 +244,34 @@ def test_simple_decoder_train_step_vs_oracle(dev):
         assert meas(f'toy simple grad {n}', relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0]) < 3.6e-2, n   # (patch embedding 2.4e-2: ReLU sign flips in front of the decoder; the rest 5e-3)
 
 
+def test_no_last_norm_train_step_and_exact_eval_vs_oracle(dev):
+    """ViT(last_norm=False) (vit.py:257: the final LayerNorm is an Identity): forward + backward against the oracle
+    under torch autograd -- the feature gradient enters the residual stream as it is -- and the fp32-accurate
+    evaluation path at 1e-3."""
+    vcfg = dict(TOY, last_norm=False)
+    hc = O.classic_head_cfg(TOY['embed_dim'])
+    bb, hd = O.synth_vit_weights(vcfg, seed=15), O.synth_head_weights(hc, seed=16)
+    assert 'last_norm.weight' not in bb
+    eng = make_engine(vcfg, hc, bb, hd, dev)
+    img, target, tw = O.synth_batch(2, seed=17)
+    # evaluation, fp32-accurate path (before the training step moves the BatchNorm running statistics)
+    ref_eval = O.head_forward({k: v.clone() for k, v in hd.items()}, O.vit_forward(bb, img, vcfg), hc, training=False)
+    got = eng.infer(img.to(dev), exact=True)
+    assert meas('no last_norm exact max abs', (got.float().cpu() - ref_eval).abs().max().item()) < EXACT_TOL
+    loss, heat = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+    torch.cuda.synchronize()
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    hdr = {k: v.clone() for k, v in hd.items()}
+    ref = O.head_forward(hdr, O.vit_forward(bbr, img, vcfg), hc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert meas('no last_norm heat rel', relerr(heat, ref.detach())[0]) < 9e-3
+    assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
+    for n in ('blocks.1.mlp.fc2.weight', 'blocks.1.mlp.fc2.bias', 'blocks.1.mlp.fc1.weight', 'blocks.0.attn.qkv.weight',
+              'patch_embed.proj.weight', 'pos_embed'):
+        assert meas(f'no last_norm grad {n}', relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0]) < 0.1, n
+
+
 @pytest.mark.parametrize('name', ['L', 'H'])
 def test_large_and_huge_widths_one_block_train_step(dev, name):
     """ViTPose-L / -H widths (E 1024 / 1280, head_dim 64 / 80) through one block + classic head,

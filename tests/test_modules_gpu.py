@@ -177,6 +177,33 @@ def test_head_module_forward_backward_vs_oracle(dev, kind):
     assert acc['acc_pose'] == pytest.approx(ref_acc)
 
 
+def test_head_module_backward_in_eval_mode_uses_running_statistics(dev):
+    """head.eval() with a gradient wanted (fine-tuning a backbone under a frozen-statistics head): BatchNorm normalises
+    with its running mean / variance, leaves them alone, and its backward has no batch-mean terms."""
+    from vitpose_amd.models import TopdownHeatmapSimpleHead
+    hc = O.classic_head_cfg(64)
+    head = TopdownHeatmapSimpleHead(loss_keypoint=dict(LOSS), **hc)
+    hd = O.synth_head_weights(hc, seed=2)
+    head.load_state_dict(hd, strict=False)
+    head = head.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 16, 12, generator=g)
+    _, target, tw = O.synth_batch(2, seed=6)
+    xd = x.to(dev).requires_grad_()
+    out = head(xd)
+    head.get_loss(out, target.to(dev), tw.to(dev))['heatmap_loss'].backward()
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    xr = x.clone().requires_grad_()
+    ref = O.head_forward(hdr, xr, hc, training=False)
+    O.joints_mse_loss(ref, target, tw).backward()
+    assert meas('eval-mode head heat rel', rel(out, ref)) < 2e-2
+    assert meas('eval-mode head dx rel', rel(xd.grad, xr.grad)) < 6e-2
+    for n, p in head.named_parameters():
+        assert meas(f'eval-mode head grad {n}', rel(p.grad, hdr[n].grad)) < 6e-2, n
+    assert torch.equal(head.deconv_layers[1].running_mean.cpu(), hd['deconv_layers.1.running_mean'])
+    assert int(head.state_dict()['deconv_layers.1.num_batches_tracked']) == int(hd.get('deconv_layers.1.num_batches_tracked', 0))
+
+
 @pytest.mark.parametrize('kind', ['classic', 'simple'])
 def test_topdown_fused_train_step_vs_oracle(dev, kind):
     model, bb, hd, ohc = toy_model(dev, kind)

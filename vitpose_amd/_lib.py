@@ -80,6 +80,7 @@ SIGNATURES = {
     'vp_bn_finalize': [P, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P],
     'vp_bn_apply_relu': [P, P, P, P, c_int, c_int, P],
     'vp_bn_bwd': [P, P, P, P, P, P, P, P, c_int, c_int, P],
+    'vp_bn_bwd_eval': [P, P, P, P, P, P, P, P, c_int, c_int, P],
     'vp_upconv_fwd': [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     'vp_upconv_bwd': [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     'vp_plane_sum_f32': [P, P, c_int, c_int, c_int, P],
@@ -103,6 +104,7 @@ SIGNATURES = {
     'vp_sumsq_chunks_det': [P, P, P, c_int, P, P, c_int, P],
     'vp_drop_path_scales': [P, P, c_int, c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, P],
     'vp_scale_bf16': [P, c_size_t, P, P],
+    'vp_identity_norm_bwd': [P, P, c_int, P, P, c_int, c_int, P],
     'vp_zero': [P, c_size_t, P],
     'vp_zero_regions': [P, P, c_int, P],
     'vp_pos_combine': [P, P, c_int, c_int, P],

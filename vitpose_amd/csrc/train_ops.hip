@@ -395,6 +395,32 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16* __restrict__ x, s
     }
 }
 
+// Backward of the identity that stands where the final LayerNorm would be (ViT(last_norm=False)): the feature gradient
+// is the residual-stream gradient (f32 copy) and, scaled by the last Block's DropPath row scale, the bf16 operand of that
+// Block's fc2 data / weight gradients.
+__global__ __launch_bounds__(256) void identity_norm_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ rowscale,
+                                                                int rows_per_scale, float* __restrict__ dx,
+                                                                bf16* __restrict__ dxb, int M, int E8) {
+    const size_t n8 = (size_t)M * E8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / E8);
+        const float s = rowscale ? rowscale[row / rows_per_scale] : 1.f;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + i * 8);
+        f32x4 lo, hi;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = (float)v[j];
+            hi[j] = (float)v[4 + j];
+            o[j] = (bf16)(lo[j] * s);
+            o[4 + j] = (bf16)(hi[j] * s);
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 8) = lo;
+        *reinterpret_cast<f32x4*>(dx + i * 8 + 4) = hi;
+        *reinterpret_cast<bf16x8*>(dxb + i * 8) = o;
+    }
+}
+
 // row 0 of a [1 + T][E] position-embedding gradient: the sum of rows 1 .. T (vit.py:320 adds pos_embed[:, :1]
 // to every token)
 __global__ __launch_bounds__(256) void pos_row0_kernel(float* __restrict__ gpos, int T, int E) {
@@ -515,8 +541,8 @@ extern "C" int vp_bn_apply_relu(const void* z, void* a, const float* scale, cons
     VP_LAUNCH_RET();
 }
 
-extern "C" int vp_bn_bwd(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
-                         float* dgamma, float* dbeta, void* dz, int M, int C, hipStream_t stream) {
+static int bn_bwd_launch(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+                         float* dgamma, float* dbeta, void* dz, int M, int C, bool batch_stats, hipStream_t stream) {
     VP_CHECK_ARG(g && z && mean && invstd && gamma && dgamma && dbeta && dz && M > 0 && C % 8 == 0);
     const int gx = (C + 255) / 256;
     int gy = (M + 255) / 256;
@@ -525,8 +551,20 @@ extern "C" int vp_bn_bwd(const void* g, const void* z, const float* mean, const 
                        invstd, dgamma, dbeta, M, C, (M + gy - 1) / gy);
     const size_t n8 = (size_t)M * C / 8;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n8)), dim3(256), 0, stream, (const bf16*)g, (const bf16*)z,
-                       mean, invstd, gamma, dgamma, dbeta, (bf16*)dz, n8, C, 1.f / (float)M);
+                       mean, invstd, gamma, dgamma, dbeta, (bf16*)dz, n8, C, batch_stats ? 1.f / (float)M : 0.f);
     VP_LAUNCH_RET();
+}
+
+extern "C" int vp_bn_bwd(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+                         float* dgamma, float* dbeta, void* dz, int M, int C, hipStream_t stream) {
+    return bn_bwd_launch(g, z, mean, invstd, gamma, dgamma, dbeta, dz, M, C, true, stream);
+}
+
+// Statistics that do not depend on the batch (eval mode: running mean / variance): the mean- and variance-gradient
+// terms of the batch-statistics formula vanish, dz = g * gamma * invstd; d gamma and d beta are the same sums.
+extern "C" int vp_bn_bwd_eval(const void* g, const void* z, const float* mean, const float* invstd, const float* gamma,
+                              float* dgamma, float* dbeta, void* dz, int M, int C, hipStream_t stream) {
+    return bn_bwd_launch(g, z, mean, invstd, gamma, dgamma, dbeta, dz, M, C, false, stream);
 }
 
 extern "C" int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, const float* target, const float* tw,
@@ -604,6 +642,15 @@ extern "C" int vp_drop_path_scales(float* dp, const float* rates, int depth, int
 extern "C" int vp_scale_bf16(void* x, size_t n, const float* scale_dev, hipStream_t stream) {
     VP_CHECK_ARG(x && scale_dev && n > 0 && n % 8 == 0 && ((uintptr_t)x & 15) == 0);
     hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, (bf16*)x, n / 8, scale_dev);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_identity_norm_bwd(const void* dy, const float* rowscale, int rows_per_scale, float* dx, void* dxb,
+                                    int M, int E, hipStream_t stream) {
+    VP_CHECK_ARG(dy && dx && dxb && M > 0 && E > 0 && E % 8 == 0 && (!rowscale || rows_per_scale > 0));
+    VP_CHECK_ARG((((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dxb) & 15) == 0);
+    hipLaunchKernelGGL(identity_norm_bwd_kernel, dim3(grid_for((size_t)M * (E / 8))), dim3(256), 0, stream,
+                       (const bf16*)dy, rowscale, rows_per_scale, dx, (bf16*)dxb, M, E / 8);
     VP_LAUNCH_RET();
 }
 

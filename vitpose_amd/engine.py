@@ -402,7 +402,9 @@ class VitRunner:
         if self.cfg.get('last_norm', True):
             plan.layernorm_fwd_pair(x, self.w('last_norm.weight'), self.w('last_norm.bias'), feat, M, E, relu=relu_out)
         else:
-            raise NotImplementedError('last_norm=False in the fp32-accurate path')
+            if relu_out:
+                raise NotImplementedError('last_norm=False with a ReLU-first head in the fp32-accurate path')
+            plan.split_pair(x, feat, M * E)
         return feat
 
     # -- backward (training workspaces of record_forward(training=True) required) --
@@ -496,7 +498,11 @@ class VitRunner:
                    None, dx_a, dxb, dp_scale(last, 1), self.g('last_norm.weight'),
                    self.g('last_norm.bias'), fc2_bias_grad(last))
         else:
-            raise NotImplementedError('last_norm=False backward')
+            # no final LayerNorm (vit.py:257: nn.Identity): the feature gradient is the residual-stream gradient
+            plan.identity_norm_bwd(dfeat, dp_scale(last, 1), T, dx_a, dxb, M, E)
+            if fc2_bias_grad(last) is not None:
+                plan.memset0(fc2_bias_grad(last))
+                plan.colsum(dxb, fc2_bias_grad(last), M, E, E)
         dx = dx_a
         other = dx_b
         for i in range(self.depth - 1, -1, -1):

@@ -245,15 +245,19 @@ class HeadRunner:
     # -- forward --
     def record_forward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, B: int, training: bool,
                        heat_nchw: torch.Tensor, target=None, tw=None, loss=None, want_grad=False,
-                       loss_weight: float = 1.0):
-        """feat: bf16 channels-last [B*Hg*Wg][Cin].  Writes heat_nchw [B][K][4Hg*4Wg...] f32."""
+                       loss_weight: float = 1.0, running_stats: bool = False):
+        """feat: bf16 channels-last [B*Hg*Wg][Cin].  Writes heat_nchw [B][K][4Hg*4Wg...] f32.
+        training: keep what the backward pass reads (pre-BatchNorm maps, activations).  running_stats (with training):
+        BatchNorm normalises with its running statistics and leaves them alone -- the module is in eval mode but a
+        gradient is wanted."""
         if self.simple:
             return self._record_forward_simple(plan, ws, feat, B, heat_nchw, target, tw, loss, want_grad, loss_weight)
         H, W = self.Hg, self.Wg
         a = feat
         sfx = (lambda l: f'.{l}') if training else (lambda l: '')
         # the accumulators of this pass (BatchNorm sums, the loss scalar) start from zero: one launch for all
-        plan.zero_small(([s_ for s_ in self.bn_sums] if training else []) + ([loss] if loss is not None else []))
+        plan.zero_small(([s_ for s_ in self.bn_sums] if training and not running_stats else []) +
+                        ([loss] if loss is not None else []))
         for l in range(self.nl):
             ci, co = self.chans[l], self.chans[l + 1]
             Min, Mout = B * H * W, B * 4 * H * W
@@ -280,8 +284,9 @@ class HeadRunner:
                                   bias=None if training else self.bn_shift[l],
                                   row_map=(W, 4 * W, 2, py * 2 * W + px))
             if training:
-                plan.bn_stats(z, self.bn_sums[l], Mout, co)
-                plan.bn_finalize(self.bn_sums[l], Mout, co, self.w(bn + 'weight'), self.w(bn + 'bias'),
+                if not running_stats:
+                    plan.bn_stats(z, self.bn_sums[l], Mout, co)
+                plan.bn_finalize(None if running_stats else self.bn_sums[l], Mout, co, self.w(bn + 'weight'), self.w(bn + 'bias'),
                                  self.buf(bn + 'running_mean'), self.buf(bn + 'running_var'), 0.1, 1e-5,
                                  self.bn_scale[l], self.bn_shift[l], self.bn_mean[l], self.bn_invstd[l])
                 act = ws.bf16(f'a.{l}', Mout, co)
@@ -341,17 +346,19 @@ class HeadRunner:
             plan.gemm(dG, self.wcat, g, M, C, self.ngp, ldx=self.ngp, ldy=C, ldo=C, y_kmajor=True)
         return g
 
-    def record_backward_nchw(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat_nchw: torch.Tensor, B: int):
+    def record_backward_nchw(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat_nchw: torch.Tensor, B: int,
+                             running_stats: bool = False):
         """Backward from an NCHW f32 heat-map gradient (stand-alone head module)."""
         if self.simple:
             return self._record_backward_simple(plan, ws, feat, dheat_nchw, B)
         H, W = self.out_hw
         dheat = ws.bf16('dheat', B * H * W, self.kpad)
         plan.nchw_to_cl(dheat_nchw, dheat, B, self.K, H * W, self.kpad)
-        return self.record_backward(plan, ws, feat, dheat, B)
+        return self.record_backward(plan, ws, feat, dheat, B, running_stats)
 
     # -- backward: returns the bf16 gradient wrt `feat` --
-    def record_backward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat: torch.Tensor, B: int):
+    def record_backward(self, plan: Plan, ws: Workspace, feat: torch.Tensor, dheat: torch.Tensor, B: int,
+                        running_stats: bool = False):
         if self.simple:
             return self._record_backward_simple(plan, ws, feat, dheat, B)
         H, W = self.out_hw
@@ -382,7 +389,7 @@ class HeadRunner:
             bn = f'deconv_layers.{3 * l + 1}.'
             dz = ws.bf16('hdz', Mout, co)
             plan.bn_bwd(g, ws.bufs[f'z.{l}'], self.bn_mean[l], self.bn_invstd[l], self.w(bn + 'weight'),
-                        self.g(bn + 'weight'), self.g(bn + 'bias'), dz, Mout, co)
+                        self.g(bn + 'weight'), self.g(bn + 'bias'), dz, Mout, co, running_stats=running_stats)
             a_in = ws.bufs[f'a.{l - 1}'] if l > 0 else feat
             implicit = co % 128 == 0 and FUSED_DECONV and WGRAD_GATHER and Wi <= 64 and 64 // Wi + 1 <= Hi and Min % 64 == 0
             if implicit:

@@ -882,15 +882,19 @@ class TopdownHeatmapSimpleHead(_FlatBound):
                       heat=ws.f32('heat', B, hr.K, *hr.out_grid))
             fwd = Plan()
             fwd.nchw_to_cl(io['x'], io['feat'], B, C, H * W, C)
-            hr.record_forward(fwd, ws, io['feat'], B, keep and self.training, io['heat'])
+            # eval mode with a gradient wanted: the deconv stack keeps its intermediates as in training, but its
+            # BatchNorms normalise with (and do not update) the running statistics
+            frozen_bn = keep and not self.training and hr.nl > 0 and not hr.simple
+            if frozen_bn:
+                hr.record_forward(fwd, ws, io['feat'], B, True, io['heat'], running_stats=True)
+            else:
+                hr.record_forward(fwd, ws, io['feat'], B, keep and self.training, io['heat'])
             bwd = None
             if keep:
-                if not self.training and hr.nl:
-                    raise NotImplementedError('backward through the deconv head in eval mode (running-stat BN)')
                 io['dheat'] = ws.f32('dheat_in', B, hr.K, *hr.out_grid)
                 io['dx'] = ws.f32('dx_nchw', B, C, H, W)
                 bwd = Plan()
-                g = hr.record_backward_nchw(bwd, ws, io['feat'], io['dheat'], B)
+                g = hr.record_backward_nchw(bwd, ws, io['feat'], io['dheat'], B, running_stats=frozen_bn)
                 bwd.strided_cast(g, io['dx'], (B, C, H * W, 1), (H * W * C, 1, C, 0))
             self._plans[key] = (fwd, bwd, io)
         return self._plans[key]

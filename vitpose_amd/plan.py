@@ -486,8 +486,9 @@ class Plan:
     def bn_apply_relu(self, z, a, scale, shift, M, C):
         self._add('vp_bn_apply_relu', _p(z), _p(a), _p(scale), _p(shift), M, C, keep=(z, a, scale, shift))
 
-    def bn_bwd(self, g, z, mean, invstd, gamma, dgamma, dbeta, dz, M, C):
-        self._add('vp_bn_bwd', _p(g), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz), M, C,
+    def bn_bwd(self, g, z, mean, invstd, gamma, dgamma, dbeta, dz, M, C, running_stats=False):
+        """running_stats: mean / invstd are the running statistics (eval mode), constants of the backward pass."""
+        self._add('vp_bn_bwd_eval' if running_stats else 'vp_bn_bwd', _p(g), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz), M, C,
                   keep=(g, z, mean, invstd, gamma, dgamma, dbeta, dz))
 
     def heatmap_loss(self, heat, ldh, heat_nchw, target, tw, loss, dheat, B, K, HW, loss_weight):
@@ -566,6 +567,13 @@ class Plan:
         """x (bf16) *= scale[0] (a device scalar)."""
         _chk(x, torch.bfloat16, 'x'), _chk(scale, torch.float32, 'scale')
         self._add('vp_scale_bf16', _p(x), x.numel(), _p(scale), keep=(x, scale))
+
+    def identity_norm_bwd(self, dy, rowscale, rows_per_scale, dx, dxb, M, E):
+        """dx (f32) = dy (bf16); dxb (bf16) = dy * rowscale[row // rows_per_scale] (rowscale None: a plain copy)."""
+        _chk(dy, torch.bfloat16, 'dy'), _chk(dx, torch.float32, 'dx'), _chk(dxb, torch.bfloat16, 'dxb')
+        _chk(rowscale, torch.float32, 'rowscale')
+        self._add('vp_identity_norm_bwd', _p(dy), _p(rowscale), rows_per_scale, _p(dx), _p(dxb), M, E,
+                  keep=(dy, rowscale, dx, dxb))
 
     def pos_combine(self, pos_embed, out, T, E):
         self._add('vp_pos_combine', _p(pos_embed), _p(out), T, E, keep=(pos_embed, out))
