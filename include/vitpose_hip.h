@@ -271,6 +271,11 @@ int vp_deconv_dgrad_bf16(const void* dout_bf16, const void* wd_bf16, void* din_b
  * matrices wph [4][Co][4*Ci] of vp_deconv_fwd_bf16 and the 16-tap matrix wd [Ci][16*Co] the data gradient reads
  * (wd[ci][(ky*4+kx)*Co + co] = W[ci][co][ky][kx]); both bf16.  Replaces five vp_strided_cast launches per layer. */
 int vp_deconv_weight_prep(const float* w, void* wph_bf16, void* wd_bf16, int Ci, int Co, vp_stream_t stream);
+/* The other two kernel sizes the head accepts (topdown_heatmap_base_head.py:105-120: kernel 3 -> padding 1,
+ * output_padding 1; kernel 2 -> padding 0): w [n][k][k] f32 (n = Ci * Co) embedded in w4 [n][4][4] f32, the 4 x 4
+ * kernel with padding 1 that computes the same transposed convolution (k = 3: taps 0..2, k = 2: taps 1..2 of each
+ * axis; zeros elsewhere).  Every 4 x 4 entry point then serves the layer. */
+int vp_deconv_weight_pad4(const float* w, float* w4, size_t n, int ksize, vp_stream_t stream);
 
 /* Grouped weight gradients: several independent dW_i [M_i][N_i] = x_i^T y_i (x_i [K][M_i], y_i [K][N_i], bf16,
  * reduction-major, f32 out, no K split) with one common reduction extent K (= tokens) in ONE launch, so that the

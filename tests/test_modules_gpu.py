@@ -177,6 +177,42 @@ def test_head_module_forward_backward_vs_oracle(dev, kind):
     assert acc['acc_pose'] == pytest.approx(ref_acc)
 
 
+@pytest.mark.parametrize('kernels', [(3, 2), (2, 3), (4, 3)])
+def test_head_deconv_kernel_sizes_3_and_2_vs_oracle(dev, kernels):
+    """Deconv kernel sizes 3 (padding 1, output_padding 1) and 2 (padding 0) of topdown_heatmap_base_head.py:105-120:
+    forward, input gradient and parameter gradients (the k x k weight gradient included) against the oracle."""
+    from vitpose_amd.models import TopdownHeatmapSimpleHead
+    hc = dict(O.classic_head_cfg(64), num_deconv_kernels=kernels)
+    head = TopdownHeatmapSimpleHead(loss_keypoint=dict(LOSS), **hc)
+    hd = O.synth_head_weights(hc, seed=3)
+    assert hd['deconv_layers.0.weight'].shape[-1] == kernels[0] and hd['deconv_layers.3.weight'].shape[-1] == kernels[1]
+    head.load_state_dict(hd, strict=False)
+    head = head.to(dev).train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 64, 16, 12, generator=g)
+    _, target, tw = O.synth_batch(2, seed=9)
+    xd = x.to(dev).requires_grad_()
+    out = head(xd)
+    assert tuple(out.shape) == (2, 17, 64, 48)
+    head.get_loss(out, target.to(dev), tw.to(dev))['heatmap_loss'].backward()
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    xr = x.clone().requires_grad_()
+    ref = O.head_forward(hdr, xr, hc, training=True)
+    O.joints_mse_loss(ref, target, tw).backward()
+    assert meas(f'deconv k{kernels} heat rel', rel(out, ref)) < 2e-2
+    assert meas(f'deconv k{kernels} dx rel', rel(xd.grad, xr.grad)) < 0.12
+    for n, p in head.named_parameters():
+        assert p.grad.shape == hdr[n].grad.shape
+        assert meas(f'deconv k{kernels} grad {n}', rel(p.grad, hdr[n].grad)) < 0.1, n
+    # evaluation (BatchNorm folded into the deconv epilogue)
+    head.eval()
+    with torch.no_grad():
+        out_e = head(x.to(dev))
+    hde = {k: v.clone() for k, v in head.state_dict().items()}
+    ref_e = O.head_forward({k: v.cpu() for k, v in hde.items()}, x, hc, training=False)
+    assert meas(f'deconv k{kernels} eval heat rel', rel(out_e, ref_e)) < 2e-2
+
+
 def test_head_module_backward_in_eval_mode_uses_running_statistics(dev):
     """head.eval() with a gradient wanted (fine-tuning a backbone under a frozen-statistics head): BatchNorm normalises
     with its running mean / variance, leaves them alone, and its backward has no batch-mean terms."""

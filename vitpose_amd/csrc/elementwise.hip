@@ -286,6 +286,28 @@ extern "C" int vp_deconv_out_gather16(const void* dout, void* g, int B, int H, i
     VP_LAUNCH_RET();
 }
 
+// A ConvTranspose2d(stride 2) weight with a 3 x 3 (padding 1, output_padding 1) or 2 x 2 (padding 0) kernel written
+// into the 4 x 4 kernel (padding 1) that computes the same layer: output pixel o receives input pixel i through tap
+// o - 2 i + 1 of a 4-tap kernel, through tap o - 2 i + 1 of the 3-tap one (its taps are taps 0..2 of the 4) and
+// through tap o - 2 i of the 2-tap one (its taps are taps 1..2 of the 4); the other taps are zero.
+__global__ __launch_bounds__(256) void deconv_weight_pad4_kernel(const float* __restrict__ w, float* __restrict__ w4,
+                                                                 size_t n, int k) {
+    const int off = k == 2 ? 1 : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 16; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i >> 4;
+        const int ky = (int)((i >> 2) & 3) - off, kx = (int)(i & 3) - off;
+        w4[i] = (ky >= 0 && ky < k && kx >= 0 && kx < k) ? w[m * k * k + ky * k + kx] : 0.f;
+    }
+}
+
+extern "C" int vp_deconv_weight_pad4(const float* w, float* w4, size_t n, int ksize, hipStream_t stream) {
+    VP_CHECK_ARG(w && w4 && n > 0 && (ksize == 2 || ksize == 3));
+    size_t blocks = (n * 16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(deconv_weight_pad4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, w4, n, ksize);
+    VP_LAUNCH_RET();
+}
+
 extern "C" int vp_deconv_weight_prep(const float* w, void* wph, void* wd, int Ci, int Co, hipStream_t stream) {
     VP_CHECK_ARG(w && wph && wd && Ci > 0 && Co > 0 && ((uintptr_t)w & 15) == 0);
     hipLaunchKernelGGL(deconv_weight_prep_kernel, dim3((Co + 31) / 32, (Ci + 31) / 32), dim3(256), 0, stream, w,

@@ -90,8 +90,8 @@ class HeadRunner:
         if extra.get('num_conv_layers', 0):
             raise NotImplementedError('extra conv layers in the head')
         if self.nl:
-            if any(k != 4 for k in cfg['num_deconv_kernels'][:self.nl]):
-                raise NotImplementedError('HIP head covers deconv kernel size 4 (the ViTPose configs)')
+            if any(k not in (2, 3, 4) for k in cfg['num_deconv_kernels'][:self.nl]):
+                raise ValueError(f"Not supported num_kernels ({cfg['num_deconv_kernels']}).")
             if self.fk != 1 or self.upsample:
                 raise NotImplementedError('deconv head with final_conv_kernel != 1 or upsample')
         if self.fk not in (1, 3):
@@ -110,6 +110,11 @@ class HeadRunner:
                    for l in range(self.nl)]
         self.dwd = [torch.zeros(self.chans[l], 16 * self.chans[l + 1], dtype=torch.float32, device=dev)
                     for l in range(self.nl)]
+        # kernel sizes 3 and 2 run as the 4 x 4 kernel that computes the same layer (vp_deconv_weight_pad4): an f32
+        # copy of the weight with the missing taps zero, refreshed with the other compute layouts
+        self.dk = [int(k) for k in cfg['num_deconv_kernels'][:self.nl]]
+        self.w4 = [torch.zeros(self.chans[l], self.chans[l + 1], 4, 4, dtype=torch.float32, device=dev)
+                   if self.dk[l] != 4 else None for l in range(self.nl)]
         cl = self.chans[-1]
         self.wf = torch.zeros(self.kpad, cl, dtype=torch.bfloat16, device=dev)
         self.bf = torch.zeros(self.kpad, dtype=torch.float32, device=dev)
@@ -150,6 +155,10 @@ class HeadRunner:
     def buf(self, n):
         return self.buffers[self.pre + n]
 
+    def deconv_w4(self, l):
+        """The [Cin][Cout][4][4] f32 weight the compute layouts of layer l are built from."""
+        return self.w4[l] if self.w4[l] is not None else self.w(f'deconv_layers.{3 * l}.weight')
+
     @property
     def out_grid(self):
         """(H, W) of the heat maps."""
@@ -166,9 +175,11 @@ class HeadRunner:
                                   (0, 0, self.cin * self.taps, self.taps))
             return
         for l in range(self.nl):
+            if self.w4[l] is not None:
+                plan.deconv_weight_pad4(self.w(f'deconv_layers.{3 * l}.weight'), self.w4[l],
+                                        self.chans[l] * self.chans[l + 1], self.dk[l])
             # wph[phase][co][(ty,tx,ci)] = W[ci][co][(1-py)+2ty][(1-px)+2tx]; wd[ci][(ky,kx,co)] = W[ci][co][ky][kx]
-            plan.deconv_weight_prep(self.w(f'deconv_layers.{3 * l}.weight'), self.wph[l], self.wd[l],
-                                    self.chans[l], self.chans[l + 1])
+            plan.deconv_weight_prep(self.deconv_w4(l), self.wph[l], self.wd[l], self.chans[l], self.chans[l + 1])
         Wf = self.w('final_layer.weight')  # [K][C][1][1]
         plan.strided_cast(Wf, self.wf, (1, 1, 1, Wf.numel()), (0, 0, 0, 1))
         plan.strided_cast(self.w('final_layer.bias'), self.bf, (1, 1, 1, self.K), (0, 0, 0, 1))
@@ -191,8 +202,10 @@ class HeadRunner:
         self.wph_pair = [torch.zeros(4, self.chans[l + 1], 8 * self.chans[l], dtype=torch.bfloat16, device=dev)
                          for l in range(self.nl)]
         for l in range(self.nl):
-            W = self.w(f'deconv_layers.{3 * l}.weight')
             ci, co = self.chans[l], self.chans[l + 1]
+            if self.w4[l] is not None:
+                plan.deconv_weight_pad4(self.w(f'deconv_layers.{3 * l}.weight'), self.w4[l], ci * co, self.dk[l])
+            W = self.deconv_w4(l)
             for py in range(2):
                 for px in range(2):
                     # wph[phase][co][(ty, tx, ci)] = W[ci][co][(1 - py) + 2 ty][(1 - px) + 2 tx]
@@ -402,7 +415,14 @@ class HeadRunner:
                 plan.wgrad(a_in, G, self.dwd[l], ci, 16 * co, Min, ldx=ci, ldy=16 * co,
                            split_k=_split_k(ci, 16 * co, Min), slab=slab)
             # [ci][(ky, kx)][co] -> the parameter's [ci][co][ky][kx] (stored)
-            plan.strided_cast(self.dwd[l], self.g(f'deconv_layers.{3 * l}.weight'), (ci, co, 16, 1), (16 * co, 1, co, 0))
+            k = self.dk[l]
+            if k == 4:
+                plan.strided_cast(self.dwd[l], self.g(f'deconv_layers.{3 * l}.weight'), (ci, co, 16, 1), (16 * co, 1, co, 0))
+            else:
+                # the k x k taps of the 4 x 4 gradient (taps 0..2 for k = 3, 1..2 for k = 2); the rest multiplied zeros
+                off = 1 if k == 2 else 0
+                plan.strided_cast(self.dwd[l].view(-1)[(off * 4 + off) * co:], self.g(f'deconv_layers.{3 * l}.weight'),
+                                  (ci, co, k, k), (16 * co, 1, 4 * co, co))
             # data gradient wrt the layer input: G Wd^T  (+ ReLU mask of the previous activation)
             gin = ws.bf16('hg_in' if l % 2 else 'hg_in2', Min, ci)
             if co % 64 == 0 and FUSED_DECONV:

@@ -466,6 +466,11 @@ class Plan:
         _chk(w, torch.float32, 'w')
         self._add('vp_deconv_weight_prep', _p(w), _p(wph), _p(wd), Ci, Co, keep=(w, wph, wd))
 
+    def deconv_weight_pad4(self, w, w4, n, k):
+        """w [n][k][k] (k 2 or 3) -> the equivalent 4 x 4 kernel w4 [n][4][4] (f32)."""
+        _chk(w, torch.float32, 'w'), _chk(w4, torch.float32, 'w4')
+        self._add('vp_deconv_weight_pad4', _p(w), _p(w4), n, k, keep=(w, w4))
+
     def deconv_phase_im2col(self, src, col, B, H, W, C, py, px):
         self._add('vp_deconv_phase_im2col', _p(src), _p(col), B, H, W, C, py, px, keep=(src, col))
 
