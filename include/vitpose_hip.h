@@ -427,6 +427,15 @@ int vp_scale_bf16(void* x, size_t n, const float* scale_dev, vp_stream_t stream)
  * [M][E]) = dy (bf16), dxb (bf16) = dy * rowscale[row / rows_per_scale] (the last Block's DropPath scale, or NULL). */
 int vp_identity_norm_bwd(const void* dy, const float* rowscale, int rows_per_scale, float* dx, void* dxb, int M, int E,
                          vp_stream_t stream);
+/* x (f32, n % 4 == 0) *= *scale_dev (the simple decoder's heat-map gradient is f32 NCHW). */
+int vp_scale_f32(float* x, size_t n, const float* scale_dev, vp_stream_t stream);
+/* out (bf16, n elements, n % 8 == 0) = sum of `count` <= 8 bf16 arrays (host array of device pointers), added in f32:
+ * the heads of TopDownMoE share one feature map (mmpose/models/detectors/top_down_moe.py:177-197), whose gradient is the
+ * sum of the heads' (autograd's accumulation into `features`). */
+int vp_sum_bf16(const void* const* srcs_host, int count, void* out, size_t n, vp_stream_t stream);
+/* out[b][0:n] = source[b] == which ? x[b][0:n] : 0 -- `target * (img_sources == i)` and the same for target_weight
+ * (top_down_moe.py:181-196); source: int32 [B] on the device. */
+int vp_mask_rows_f32(const float* x, const int* source, int which, float* out, int B, size_t n, vp_stream_t stream);
 /* hipMemsetAsync(p, 0, bytes) on `stream` (accumulating reductions start from zero). */
 int vp_zero(void* p, size_t bytes, vp_stream_t stream);
 /* Up to VP_ZERO_MAX_REGIONS small f32 regions zeroed by one launch (BatchNorm sums and parameter gradients, the

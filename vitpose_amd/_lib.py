@@ -106,6 +106,9 @@ SIGNATURES = {
     'vp_drop_path_scales': [P, P, c_int, c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, P],
     'vp_scale_bf16': [P, c_size_t, P, P],
     'vp_identity_norm_bwd': [P, P, c_int, P, P, c_int, c_int, P],
+    'vp_scale_f32': [P, c_size_t, P, P],
+    'vp_sum_bf16': [P, c_int, P, c_size_t, P],
+    'vp_mask_rows_f32': [P, P, c_int, P, c_int, c_size_t, P],
     'vp_zero': [P, c_size_t, P],
     'vp_zero_regions': [P, P, c_int, P],
     'vp_pos_combine': [P, P, c_int, c_int, P],

@@ -395,6 +395,44 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(bf16* __restrict__ x, s
     }
 }
 
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ x, size_t n4, const float* __restrict__ scale) {
+    const float s = *scale;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = *reinterpret_cast<f32x4*>(x + i * 4);
+        *reinterpret_cast<f32x4*>(x + i * 4) = v * s;
+    }
+}
+
+// out = bf16(sum of up to 8 bf16 arrays, added in f32): several heads on one feature map (TopDownMoE) hand the
+// backbone the sum of their feature gradients
+struct SumSrc {
+    const bf16* p[8];
+};
+__global__ __launch_bounds__(256) void sum_bf16_kernel(SumSrc src, int count, bf16* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int k = 0; k < count; ++k) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src.p[k] + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+        *reinterpret_cast<bf16x8*>(out + i * 8) = o;
+    }
+}
+
+// out[b][:] = x[b][:] if source[b] == which else 0 (row length n): the per-head selection of targets / target weights
+__global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, const int* __restrict__ source,
+                                                        int which, float* __restrict__ out, int B, size_t n) {
+    const size_t total = (size_t)B * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = source[i / n] == which ? x[i] : 0.f;
+}
+
 // Backward of the identity that stands where the final LayerNorm would be (ViT(last_norm=False)): the feature gradient
 // is the residual-stream gradient (f32 copy) and, scaled by the last Block's DropPath row scale, the bf16 operand of that
 // Block's fc2 data / weight gradients.
@@ -651,6 +689,30 @@ extern "C" int vp_identity_norm_bwd(const void* dy, const float* rowscale, int r
     VP_CHECK_ARG((((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dxb) & 15) == 0);
     hipLaunchKernelGGL(identity_norm_bwd_kernel, dim3(grid_for((size_t)M * (E / 8))), dim3(256), 0, stream,
                        (const bf16*)dy, rowscale, rows_per_scale, dx, (bf16*)dxb, M, E / 8);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_scale_f32(float* x, size_t n, const float* scale_dev, hipStream_t stream) {
+    VP_CHECK_ARG(x && scale_dev && n > 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0);
+    hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, x, n / 4, scale_dev);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_sum_bf16(const void* const* srcs_host, int count, void* out, size_t n, hipStream_t stream) {
+    VP_CHECK_ARG(srcs_host && out && count > 0 && count <= 8 && n > 0 && n % 8 == 0 && ((uintptr_t)out & 15) == 0);
+    SumSrc s{};
+    for (int i = 0; i < count; ++i) {
+        VP_CHECK_ARG(srcs_host[i] && ((uintptr_t)srcs_host[i] & 15) == 0);
+        s.p[i] = (const bf16*)srcs_host[i];
+    }
+    hipLaunchKernelGGL(sum_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, s, count, (bf16*)out, n / 8);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_mask_rows_f32(const float* x, const int* source, int which, float* out, int B, size_t n,
+                                hipStream_t stream) {
+    VP_CHECK_ARG(x && source && out && B > 0 && n > 0);
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for((size_t)B * n)), dim3(256), 0, stream, x, source, which, out, B, n);
     VP_LAUNCH_RET();
 }
 

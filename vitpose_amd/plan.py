@@ -580,6 +580,14 @@ class Plan:
         self._add('vp_identity_norm_bwd', _p(dy), _p(rowscale), rows_per_scale, _p(dx), _p(dxb), M, E,
                   keep=(dy, rowscale, dx, dxb))
 
+    def sum_bf16(self, srcs, out):
+        """out (bf16) = sum of the bf16 tensors `srcs` (at most 8, same size), accumulated in f32."""
+        for t in srcs:
+            _chk(t, torch.bfloat16, 'src')
+        _chk(out, torch.bfloat16, 'out')
+        arr = (c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+        self._add('vp_sum_bf16', arr, len(srcs), _p(out), out.numel(), keep=(arr, out) + tuple(srcs))
+
     def pos_combine(self, pos_embed, out, T, E):
         self._add('vp_pos_combine', _p(pos_embed), _p(out), T, E, keep=(pos_embed, out))
 

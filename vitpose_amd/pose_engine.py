@@ -191,15 +191,10 @@ class PoseEngine:
             if nh > 1:
                 # every head reads the same feature map: its gradient is the sum over the heads (a small
                 # elementwise add, f32 accumulation)
-                acc = ws.f32('dfeat_sum_f32', *dfeat.shape)
                 dsum = ws.bf16('dfeat_sum', *dfeat.shape)
-
-                def add_up():
-                    acc.copy_(dfeats[0])
-                    for d in dfeats[1:]:
-                        acc.add_(d)
-                    dsum.copy_(acc)
-                plan.host(add_up)
+                if nh > 8:
+                    raise NotImplementedError('more than 8 heads on one feature map')
+                plan.sum_bf16(dfeats, dsum)
                 dfeat = dsum
             comm = self.comm
             self.vit.record_backward(plan, ws, dfeat, B, dp=io['dp'],
@@ -214,13 +209,11 @@ class PoseEngine:
         """dheat *= scale[0] (device scalar): the incoming dL/dloss of an autograd backward.  Heat-map gradients are
         bf16 channels-last (classic head) or f32 NCHW (simple decoder)."""
         import ctypes
-        if dheat.dtype != torch.bfloat16:
-            dheat.mul_(scale)
-            return
-        rc = _lib.lib().vp_scale_bf16(dheat.data_ptr(), dheat.numel(), scale.data_ptr(),
-                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        fn = _lib.lib().vp_scale_bf16 if dheat.dtype == torch.bfloat16 else _lib.lib().vp_scale_f32
+        rc = fn(dheat.data_ptr(), dheat.numel(), scale.data_ptr(),
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
-            raise RuntimeError(f'vp_scale_bf16 failed with status {rc}')
+            raise RuntimeError(f'scaling the heat-map gradient failed with status {rc}')
 
     def load_batch(self, io, img, target, target_weight, dataset_source=None):
         """Copy one batch into the plan's input buffers; with several heads / a routed backbone also the
@@ -249,13 +242,20 @@ class PoseEngine:
         src = dataset_source if dataset_source is not None else [0] * B
         if self.routed:
             self.vit.set_routing(self.ws_train, B, src)
-        src_t = torch.as_tensor(src, device=self.device).reshape(B)
-        tw0 = io['tw'].clone() if len(self.heads) > 1 else io['tw']
-        for j in range(len(self.heads)):
-            sel = (src_t == j).to(torch.float32)
+        import ctypes
+        src_t = torch.as_tensor(src, dtype=torch.int32).reshape(B).to(self.device)      # (input data: one upload)
+        L, s_ = _lib.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # head 0 masks its weights in place last: every other head reads the unmasked ones first
+        for j in list(range(1, len(self.heads))) + [0]:
             if io['targets'][j] is not io['target']:
-                torch.mul(io['target'], sel.view(B, 1, 1, 1), out=io['targets'][j])
-            torch.mul(tw0, sel.view(B, 1), out=io['tws'][j])
+                n = io['target'][0].numel()
+                rc = L.vp_mask_rows_f32(io['target'].data_ptr(), src_t.data_ptr(), j, io['targets'][j].data_ptr(), B, n, s_)
+                if rc != 0:
+                    raise RuntimeError(f'vp_mask_rows_f32 failed with status {rc}')
+            rc = L.vp_mask_rows_f32(io['tw'].data_ptr(), src_t.data_ptr(), j, io['tws'][j].data_ptr(), B, self.K, s_)
+            if rc != 0:
+                raise RuntimeError(f'vp_mask_rows_f32 failed with status {rc}')
+        io['_src_keep'] = src_t            # stays alive until the kernels that read it have run
 
     def forward_backward(self, img, target, target_weight, drop_path: bool = True, dp_scales=None,
                          timers=None, dataset_source=None):
