@@ -227,6 +227,16 @@ def test_patch_im2col_and_casts(dev):
     cs = torch.ones(264, device=dev)
     run(lambda p: p.colsum(a, cs, 777, 264, 264))
     torch.testing.assert_close(cs, a.float().sum(0) + 1, rtol=1e-4, atol=1e-3)
+    for Mn, Nn in ((12288, 32), (1001, 8), (4097, 64), (333, 16)):     # packed narrow matrices (the heat-map gradient)
+        an = rnd((Mn, Nn), dev, 30 + Nn).bfloat16()
+        cn = torch.full((Nn,), 2.0, device=dev)
+        run(lambda p: p.colsum(an, cn, Mn, Nn, Nn))
+        torch.testing.assert_close(cn, an.float().sum(0) + 2, rtol=1e-4, atol=2e-3)
+    gp = rnd((193, 768), dev, 41)                                       # position-embedding gradient: row 0 = sum of rows 1..T
+    dxs = rnd((3, 192 * 768), dev, 42)
+    run(lambda p: p.pos_embed_grad(dxs, gp, 3, 192, 768))
+    torch.testing.assert_close(gp[1:], dxs.sum(0).view(192, 768), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gp[0], dxs.sum(0).view(192, 768).sum(0), rtol=1e-5, atol=1e-4)
     xs = rnd((3, 192 * 64), dev, 4)
     bs = torch.empty(192 * 64, device=dev)
     run(lambda p: p.batch_sum(xs, bs, 3, 192 * 64))

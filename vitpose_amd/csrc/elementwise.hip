@@ -245,8 +245,46 @@ extern "C" int vp_strided_cast(const void* in, int in_dtype, void* out, int out_
     VP_LAUNCH_RET();
 }
 
+// Narrow matrices (N <= 64 columns, rows packed: lda == N; the padded heat-map gradient): the kernel above would keep
+// one thread in eight busy.  Every thread walks 16-byte chunks of the flat array with a stride that is a multiple
+// of the chunks per row, so it stays on one column group; a block sums its threads per column group.
+template <int CG>     // 16-byte chunks per row
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const bf16* __restrict__ a, float* __restrict__ out, size_t n8) {
+    __shared__ float red[256][9];
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t stride = (size_t)gridDim.x * 256;       // 256 % CG == 0
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = s[j];
+    __syncthreads();
+    if (threadIdx.x < CG * 8) {
+        const int cg = threadIdx.x >> 3, j = threadIdx.x & 7;
+        float t = 0.f;
+        for (int r = cg; r < 256; r += CG) t += red[r][j];
+        atomicAdd(out + cg * 8 + j, t);
+    }
+}
+
 extern "C" int vp_colsum_bf16(const void* a, float* out, int M, int N, int lda, hipStream_t stream) {
     VP_CHECK_ARG(a && out && M > 0 && N > 0 && N % 8 == 0 && lda % 8 == 0);
+    if (lda == N && (N == 8 || N == 16 || N == 32 || N == 64) && ((uintptr_t)a & 15) == 0) {
+        const size_t n8 = (size_t)M * (N / 8);
+        size_t blocks = (n8 + 2047) / 2048;          // ~8 chunks per thread
+        if (blocks > 1024) blocks = 1024;
+        if (blocks < 1) blocks = 1;
+        const dim3 g((unsigned)blocks), b(256);
+        switch (N / 8) {
+            case 1: hipLaunchKernelGGL(colsum_narrow_kernel<1>, g, b, 0, stream, (const bf16*)a, out, n8); break;
+            case 2: hipLaunchKernelGGL(colsum_narrow_kernel<2>, g, b, 0, stream, (const bf16*)a, out, n8); break;
+            case 4: hipLaunchKernelGGL(colsum_narrow_kernel<4>, g, b, 0, stream, (const bf16*)a, out, n8); break;
+            default: hipLaunchKernelGGL(colsum_narrow_kernel<8>, g, b, 0, stream, (const bf16*)a, out, n8); break;
+        }
+        VP_LAUNCH_RET();
+    }
     const int gx = (N + 255) / 256;
     int gy = (M + 255) / 256;
     if (gy > 512) gy = 512;

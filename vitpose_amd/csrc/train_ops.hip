@@ -461,19 +461,24 @@ __global__ __launch_bounds__(256) void identity_norm_bwd_kernel(const bf16* __re
 
 // row 0 of a [1 + T][E] position-embedding gradient: the sum of rows 1 .. T (vit.py:320 adds pos_embed[:, :1]
 // to every token)
+// (one workgroup per 64 columns: 16 row groups x 16 four-column lanes, summed through LDS in a fixed order)
 __global__ __launch_bounds__(256) void pos_row0_kernel(float* __restrict__ gpos, int T, int E) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int t = 1;
-    for (; t + 3 <= T; t += 4) {
-        s0 += gpos[(size_t)t * E + e];
-        s1 += gpos[(size_t)(t + 1) * E + e];
-        s2 += gpos[(size_t)(t + 2) * E + e];
-        s3 += gpos[(size_t)(t + 3) * E + e];
+    __shared__ f32x4 red[16][16];
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int e = blockIdx.x * 64 + cq * 4;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e < E) {
+#pragma unroll 4
+        for (int t = 1 + rg; t <= T; t += 16) s += *reinterpret_cast<const f32x4*>(gpos + (size_t)t * E + e);
     }
-    for (; t <= T; ++t) s0 += gpos[(size_t)t * E + e];
-    gpos[e] = (s0 + s1) + (s2 + s3);
+    red[rg][cq] = s;
+    __syncthreads();
+    if (rg == 0 && e < E) {
+        f32x4 t = red[0][cq];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) t += red[r][cq];
+        *reinterpret_cast<f32x4*>(gpos + e) = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int n,
@@ -726,7 +731,7 @@ extern "C" int vp_pos_embed_grad(const float* dx, float* gpos, int B, int T, int
     VP_CHECK_ARG(dx && gpos && B > 0 && T > 0 && E > 0 && E % 4 == 0);
     const int rc = vp_batch_sum_f32(dx, gpos + E, B, (size_t)T * E, stream);      // rows 1 .. T
     if (rc != VP_OK) return rc;
-    hipLaunchKernelGGL(pos_row0_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, gpos, T, E);
+    hipLaunchKernelGGL(pos_row0_kernel, dim3((E + 63) / 64), dim3(256), 0, stream, gpos, T, E);
     VP_LAUNCH_RET();
 }
 
