@@ -218,6 +218,12 @@ def test_patch_im2col_and_casts(dev):
     run(lambda p: p.patch_im2col(img, col, B, 3, 256, 192, 16, 16, 2))
     ref = torch.nn.functional.unfold(img, 16, padding=2, stride=16).transpose(1, 2).reshape(B * 192, 768)
     assert torch.equal(col.float(), ref.bfloat16().float())
+    for pad, pch in ((0, 16), (4, 16), (1, 16), (2, 8)):       # even pads: the strip kernel; odd pad / patch 8: the general one
+        Hp, Wp = (256 + 2 * pad - pch) // pch + 1, (192 + 2 * pad - pch) // pch + 1
+        c2 = torch.full((B * Hp * Wp, 3 * pch * pch), float('nan'), device=dev, dtype=torch.bfloat16)
+        run(lambda p: p.patch_im2col(img, c2, B, 3, 256, 192, pch, pch, pad))
+        r2 = torch.nn.functional.unfold(img, pch, padding=pad, stride=pch).transpose(1, 2).reshape(B * Hp * Wp, -1)
+        assert torch.equal(c2.float(), r2.bfloat16().float()), (pad, pch)
     # strided cast: NCHW <-> token-major permute
     x = rnd((B, 192, 64), dev, 2)
     o = torch.empty(B, 64, 192, device=dev)

@@ -216,11 +216,64 @@ inline int grid_for(size_t work_items) {
 
 }  // namespace
 
+// Non-overlapping 16 x 16 patches (stride == patch: every ViTPose configuration): one workgroup per row of patches.
+// The 16 image rows of that strip are read as whole rows (coalesced; two pixels per lane), converted, scattered into
+// the strip's output image in LDS -- Wp consecutive tokens x K columns are one contiguous piece of `col` -- and
+// written out 16 bytes per lane.  The general kernel above reads 64-byte pieces; this one moves the same bytes ~3x
+// faster.
+constexpr int PATCH_STRIP_MAX = 12 * 3 * 256;     // bf16 elements of one strip in LDS (Wp * C * 256)
+template <int C, int NSUB>     // channels; strip rows in flight per pass (256 / (8 Wp))
+__global__ __launch_bounds__(256) void patch_im2col_strip_kernel(const float* __restrict__ img, bf16* __restrict__ col,
+                                                                 int H, int W, int Hp, int Wp, int pad) {
+    __shared__ __attribute__((aligned(16))) bf16 tile[PATCH_STRIP_MAX];
+    const int b = blockIdx.x / Hp, py = blockIdx.x % Hp;
+    const int K = C * 256;
+    const int pairs = Wp * 8;                      // pixel pairs per strip row
+    const int rsub = threadIdx.x / pairs, xp = threadIdx.x % pairs;
+    if (rsub < NSUB) {
+        const int x = xp * 2 - pad;                // first pixel of the pair (pad is even: the pair never straddles x = 0)
+        const int px = xp >> 3, kx = (xp & 7) * 2;
+        const bool xok = x >= 0 && x + 1 < W;
+#pragma unroll 8
+        for (int it = 0; it < (C * 16 + NSUB - 1) / NSUB; ++it) {
+            const int r = rsub + it * NSUB;
+            if (r >= C * 16) break;
+            const int c = r >> 4, ky = r & 15;
+            const int y = py * 16 - pad + ky;
+            float v0 = 0.f, v1 = 0.f;
+            if (y >= 0 && y < H) {
+                const float* row = img + (((size_t)b * C + c) * H + y) * W;
+                if (xok) {
+                    const float2 v = *reinterpret_cast<const float2*>(row + x);
+                    v0 = v.x;
+                    v1 = v.y;
+                } else {
+                    if (x >= 0 && x < W) v0 = row[x];
+                    if (x + 1 >= 0 && x + 1 < W) v1 = row[x + 1];
+                }
+            }
+            bf16* d = tile + (px * C + c) * 256 + ky * 16 + kx;
+            d[0] = (bf16)v0;
+            d[1] = (bf16)v1;
+        }
+    }
+    __syncthreads();
+    const int chunks = Wp * K / 8;
+    uint4* dst = reinterpret_cast<uint4*>(col + (size_t)blockIdx.x * Wp * K);
+    for (int i = threadIdx.x; i < chunks; i += 256) dst[i] = *reinterpret_cast<const uint4*>(tile + i * 8);
+}
+
 extern "C" int vp_patch_im2col(const float* img, void* col_bf16, int B, int C, int H, int W, int patch, int stride,
                                int pad, hipStream_t stream) {
     VP_CHECK_ARG(img && col_bf16 && B > 0 && C > 0 && patch % 8 == 0 && stride > 0);
     const int Hp = (H + 2 * pad - patch) / stride + 1, Wp = (W + 2 * pad - patch) / stride + 1;
     VP_CHECK_ARG(Hp > 0 && Wp > 0);
+    if (patch == 16 && stride == 16 && pad >= 0 && pad % 2 == 0 && W % 2 == 0 && C == 3 && 256 / (Wp * 8) == 2 &&
+        Wp * C * 256 <= PATCH_STRIP_MAX && ((uintptr_t)img & 7) == 0 && ((uintptr_t)col_bf16 & 15) == 0) {
+        hipLaunchKernelGGL((patch_im2col_strip_kernel<3, 2>), dim3(B * Hp), dim3(256), 0, stream, img, (bf16*)col_bf16, H,
+                           W, Hp, Wp, pad);
+        VP_LAUNCH_RET();
+    }
     const size_t total = (size_t)B * Hp * Wp * (C * patch * patch / 8);
     hipLaunchKernelGGL(patch_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, (bf16*)col_bf16, B, C, H,
                        W, Hp, Wp, patch, stride, pad);
@@ -273,8 +326,8 @@ extern "C" int vp_colsum_bf16(const void* a, float* out, int M, int N, int lda, 
     VP_CHECK_ARG(a && out && M > 0 && N > 0 && N % 8 == 0 && lda % 8 == 0);
     if (lda == N && (N == 8 || N == 16 || N == 32 || N == 64) && ((uintptr_t)a & 15) == 0) {
         const size_t n8 = (size_t)M * (N / 8);
-        size_t blocks = (n8 + 2047) / 2048;          // ~8 chunks per thread
-        if (blocks > 1024) blocks = 1024;
+        size_t blocks = (n8 + 2047) / 2048;          // >= 8 chunks per thread; few blocks: each ends in N atomics on
+        if (blocks > 256) blocks = 256;              // the same N addresses, which serialise
         if (blocks < 1) blocks = 1;
         const dim3 g((unsigned)blocks), b(256);
         switch (N / 8) {
