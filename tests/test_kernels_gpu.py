@@ -406,8 +406,10 @@ def test_batchnorm_relu_fwd_bwd(dev):
     torch.testing.assert_close(scale, gamma / torch.sqrt(rv + 1e-5), rtol=1e-5, atol=1e-6)
 
 
-def test_heatmap_loss_and_argmax(dev):
-    B, K, H, W, LD = 3, 17, 64, 48, 64
+@pytest.mark.parametrize('B,K,H,W,LD', [(3, 17, 64, 48, 64), (2, 17, 10, 13, 32), (1, 32, 9, 7, 32), (2, 40, 8, 8, 64),
+                                        (1, 133, 16, 12, 192)])
+def test_heatmap_loss_and_argmax(dev, B, K, H, W, LD):
+    """(K <= 32 in rows of <= 64 columns: the tiled kernel; wider heads: one pixel per thread)"""
     heat_nchw = rnd((B, K, H, W), dev, 1)
     heat = torch.zeros(B * H * W, LD, device=dev)
     heat[:, :K] = heat_nchw.permute(0, 2, 3, 1).reshape(-1, K)
@@ -425,7 +427,7 @@ def test_heatmap_loss_and_argmax(dev):
     torch.testing.assert_close(loss[0], ref, rtol=1e-5, atol=1e-7)
     dref = pr.grad.permute(0, 2, 3, 1).reshape(-1, K)
     torch.testing.assert_close(dheat[:, :K].float(), dref.bfloat16().float(), rtol=1e-2, atol=1e-9)
-    assert dheat[:, K:].float().abs().max() == 0
+    assert K == LD or dheat[:, K:].float().abs().max() == 0
     idx = torch.empty(B * K, device=dev, dtype=torch.int32)
     val = torch.empty(B * K, device=dev)
     run(lambda p: p.argmax_rows(heat_nchw, B * K, H * W, idx, val))

@@ -610,6 +610,74 @@ extern "C" int vp_bn_bwd_eval(const void* g, const void* z, const float* mean, c
     return bn_bwd_launch(g, z, mean, invstd, gamma, dgamma, dbeta, dz, M, C, false, stream);
 }
 
+// The same for K <= 32 maps in rows of at most 64 padded columns (every ViTPose body model), with all three arrays
+// moved in whole cache lines: a workgroup takes 256 consecutive pixels, reads the first ceil(K / 4) 16-byte chunks of
+// their channels-last rows chunk by chunk into LDS, then works one pixel per thread on the NCHW side (consecutive
+// threads = consecutive pixels of one map: coalesced), and writes the padded bf16 gradient rows back as one
+// contiguous 32 KiB piece.  (One pixel per thread on the channels-last side touches 64 cache lines per instruction.)
+constexpr int HL_PIX = 256, HL_MAXQ = 8, HL_GP = 72;    // pixels per workgroup, 16-byte chunks per row, bf16 pitch of the gradient tile
+__global__ __launch_bounds__(256) void heatmap_loss_tiled_kernel(const float* __restrict__ heat, int ldh,
+                                                                 float* __restrict__ heat_nchw,
+                                                                 const float* __restrict__ target,
+                                                                 const float* __restrict__ tw, float* __restrict__ loss,
+                                                                 bf16* __restrict__ dheat, int B, int K, int HW,
+                                                                 float coef) {
+    __shared__ float tile[HL_PIX * (4 * HL_MAXQ + 1)];
+    __shared__ __attribute__((aligned(16))) bf16 gt[HL_PIX * HL_GP];
+    const size_t p0 = (size_t)blockIdx.x * HL_PIX, npix = (size_t)B * HW;
+    const int nq = (K + 3) >> 2, pitch = 4 * nq + 1;
+    for (int i = threadIdx.x; i < HL_PIX * nq; i += 256) {
+        const int px = i / nq, q = i - px * nq;
+        if (p0 + px < npix) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(heat + (p0 + px) * ldh + 4 * q);
+            float* d = tile + px * pitch + 4 * q;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+    }
+    if (dheat) {   // padded columns of the gradient rows are zero
+        for (int i = threadIdx.x; i < HL_PIX * HL_GP / 8; i += 256) {
+            bf16x8 z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+            *reinterpret_cast<bf16x8*>(gt + i * 8) = z;
+        }
+    }
+    __syncthreads();
+    float part = 0.f;
+    const size_t i = p0 + threadIdx.x;
+    if (i < npix) {
+        const int b = (int)(i / HW), hw = (int)(i % HW);
+        const float* row = tile + threadIdx.x * pitch;
+        for (int k = 0; k < K; ++k) {
+            const float p = row[k];
+            const size_t o = ((size_t)b * K + k) * HW + hw;
+            if (heat_nchw) heat_nchw[o] = p;
+            if (target) {
+                const float w = tw ? tw[b * K + k] : 1.f;
+                const float d = w * (p - target[o]);
+                part += d * d;
+                gt[threadIdx.x * HL_GP + k] = (bf16)(2.f * w * d * coef);
+            }
+        }
+    }
+    if (dheat) {
+        __syncthreads();
+        const int cpr = ldh >> 3;           // 16-byte chunks per gradient row
+        for (int j = threadIdx.x; j < HL_PIX * cpr; j += 256) {
+            const int px = j / cpr, c = j - px * cpr;
+            if (p0 + px < npix)
+                *reinterpret_cast<uint4*>(dheat + (p0 + px) * ldh + 8 * c) = *reinterpret_cast<const uint4*>(gt + px * HL_GP + 8 * c);
+        }
+    }
+    if (target && loss) {
+        part = wave_sum(part);
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * coef);
+    }
+}
+
 extern "C" int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, const float* target, const float* tw,
                                float* loss, void* dheat, int B, int K, int HW, float loss_weight, hipStream_t stream) {
     VP_CHECK_ARG(heat && B > 0 && K > 0 && K <= ldh && HW > 0 && ldh % 8 == 0);
@@ -617,6 +685,11 @@ extern "C" int vp_heatmap_loss(const float* heat, int ldh, float* heat_nchw, con
     VP_CHECK_ARG(heat_nchw || target);
     const float coef = loss_weight / ((float)B * (float)K * (float)HW);
     const size_t n = (size_t)B * HW;
+    if (K <= 4 * HL_MAXQ && ldh <= 64) {
+        hipLaunchKernelGGL(heatmap_loss_tiled_kernel, dim3((unsigned)((n + HL_PIX - 1) / HL_PIX)), dim3(256), 0, stream,
+                           heat, ldh, heat_nchw, target, tw, loss, (bf16*)dheat, B, K, HW, coef);
+        VP_LAUNCH_RET();
+    }
     hipLaunchKernelGGL(heatmap_loss_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, heat, ldh,
                        heat_nchw, target, tw, loss, (bf16*)dheat, B, K, HW, coef);
     VP_LAUNCH_RET();
