@@ -38,6 +38,9 @@ _TAIL_WS = {}
 # (tile schedule of vp_gemm_bf16, K split of the weight-gradient GEMMs); VITPOSE_AUTOTUNE=0 disables.
 _TUNE_CACHE = {}
 AUTOTUNE = os.environ.get('VITPOSE_AUTOTUNE', '1') != '0'
+# VITPOSE_TUNE_OVERRIDE="<xk><yk>:<epilogue>:<N>:<K>=<tile_mode>,...": pins the tile schedule of a product class (whole-step
+# A/B runs of one schedule against the record-time pick), e.g. "00:2:768:3072=2" = fc2 + residual on the 256 tiles
+_TUNE_OVERRIDE = {k: int(v) for k, v in (kv.split('=') for kv in os.environ.get('VITPOSE_TUNE_OVERRIDE', '').split(',') if kv)}
 
 
 def _time_launch(fn, reps=5):
@@ -248,6 +251,9 @@ class Plan:
                 and route is None):
             key = ('gemm', M, N, K, int(x_kmajor), int(y_kmajor), epilogue, resid is not None, out2 is not None,
                    str(out.device), int(split3), int(pair_act))
+            ov = _TUNE_OVERRIDE.get(f'{int(x_kmajor)}{int(y_kmajor)}:{epilogue}:{N}:{K}')
+            if ov is not None and key not in _TUNE_CACHE:
+                _TUNE_CACHE[key] = ov
             if key not in _TUNE_CACHE:
                 fn = self.L.vp_gemm_bf16
                 s_ = c_void_p(torch.cuda.current_stream().cuda_stream)
