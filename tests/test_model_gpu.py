@@ -209,6 +209,46 @@ def test_train_step_updates_weights_like_torch_adamw(dev):
     assert meas('toy adamw first-update rel', rel) < 0.25
 
 
+def test_loss_trajectory_over_steps_tracks_the_oracle(dev):
+    """Eight optimizer steps on two alternating batches (fwd + bwd + clip + layer-decay AdamW, BatchNorm statistics moving):
+    the loss of every step stays within a few per cent of the oracle trained by torch autograd + torch.optim.AdamW with the
+    same groups -- errors do not compound into a different trajectory -- and the loss goes down."""
+    from vitpose_amd.optim import layer_decay_param_groups
+    hc = dict(O.classic_head_cfg(64))
+    bb, hd = O.synth_vit_weights(TOY, seed=21), O.synth_head_weights(hc, seed=22)
+    eng = make_engine(TOY, hc, bb, hd, dev)
+    eng.setup_optimizer(lr=2e-4, weight_decay=0.1, layer_decay_rate=0.75, max_grad_norm=1.0)
+    batches = [O.synth_batch(2, seed=23), O.synth_batch(2, seed=24)]
+    params = {('backbone.' + k): v.clone().requires_grad_() for k, v in bb.items()}
+    hparams = {k: v.clone() for k, v in hd.items()}
+    for k, v in hparams.items():
+        if 'running' not in k:
+            params['keypoint_head.' + k] = v.requires_grad_()
+    bbp = {k[len('backbone.'):]: v for k, v in params.items() if k.startswith('backbone.')}
+    groups = layer_decay_param_groups([(n, tuple(p.shape)) for n, p in params.items()], TOY['depth'], 0.75, 2e-4, 0.1)
+    topt = torch.optim.AdamW([dict(params=[p], lr=groups[n]['lr'], weight_decay=groups[n]['weight_decay'])
+                              for n, p in params.items()], lr=2e-4)
+    got, ref = [], []
+    for step in range(8):
+        img, target, tw = batches[step % 2]
+        loss, _ = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+        got.append(loss.item())
+        eng.optimizer_step()
+        topt.zero_grad()
+        rl = O.joints_mse_loss(O.head_forward(hparams, O.vit_forward(bbp, img, TOY), hc, training=True), target, tw)
+        rl.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        topt.step()
+        ref.append(rl.item())
+    worst = max(abs(a - b) / b for a, b in zip(got, ref))
+    print('loss per step, HIP:', [f'{v:.5f}' for v in got], 'oracle:', [f'{v:.5f}' for v in ref])
+    assert meas('toy 8-step loss trajectory worst rel', worst) < 3e-3      # 7e-4 measured
+    assert got[-2] < got[0] and got[-1] < got[1]
+    # BatchNorm running statistics followed the same path
+    rm = eng.buffers['keypoint_head.deconv_layers.1.running_mean'].cpu()
+    assert meas('toy 8-step running_mean rel', relerr(rm, hparams['deconv_layers.1.running_mean'])[0]) < 2e-2
+
+
 def test_vitpose_s_simple_decoder_vs_reference_golden(dev, golden_dir):
     """The CPU-runnable benchmark configuration (ViTPose-S + simple decoder, batch 1): the reference source ran it on the
     CPU (golden), the HIP path runs it on the GPU.  O(1) heat maps, bf16 operands: relative bound."""
