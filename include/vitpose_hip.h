@@ -271,6 +271,14 @@ int vp_deconv_dgrad_bf16(const void* dout_bf16, const void* wd_bf16, void* din_b
  * matrices wph [4][Co][4*Ci] of vp_deconv_fwd_bf16 and the 16-tap matrix wd [Ci][16*Co] the data gradient reads
  * (wd[ci][(ky*4+kx)*Co + co] = W[ci][co][ky][kx]); both bf16.  Replaces five vp_strided_cast launches per layer. */
 int vp_deconv_weight_prep(const float* w, void* wph_bf16, void* wd_bf16, int Ci, int Co, vp_stream_t stream);
+/* nn.Conv2d(C, *, 3, stride 1, padding 1) of the head's optional conv layers and 3 x 3 final layer after a deconv stack
+ * (topdown_heatmap_simple_head.py:112-138) as a GEMM on channels-last maps: col [B*H*W][9*C] bf16,
+ * col[(b,y,x)][(3 ky + kx) * C + c] = in[b][y+ky-1][x+kx-1][c] (zero outside), to be multiplied with the weight re-laid
+ * as [Cout][(3 ky + kx) * C + c]; and its transpose (the data gradient): din[(b,y,x)][c] = sum over the taps of dcol,
+ * masked where relu_aux <= 0 when relu_aux is given (the ReLU in front of the layer).  C % 8 == 0. */
+int vp_im2col3x3_bf16(const void* in_bf16, void* col_bf16, int B, int H, int W, int C, vp_stream_t stream);
+int vp_col2im3x3_bf16(const void* dcol_bf16, void* din_bf16, const void* relu_aux_bf16, int B, int H, int W, int C,
+                      vp_stream_t stream);
 /* The other two kernel sizes the head accepts (topdown_heatmap_base_head.py:105-120: kernel 3 -> padding 1,
  * output_padding 1; kernel 2 -> padding 0): w [n][k][k] f32 (n = Ci * Co) embedded in w4 [n][4][4] f32, the 4 x 4
  * kernel with padding 1 that computes the same transposed convolution (k = 3: taps 0..2, k = 2: taps 1..2 of each

@@ -220,7 +220,18 @@ def head_forward(sd: Dict[str, Tensor], feat: Tensor, cfg: dict, training: bool 
     fk = extra.get('final_conv_kernel', 1)
     if fk == 0:
         return x
-    return F.conv2d(x, sd['final_layer.weight'], sd['final_layer.bias'], padding=1 if fk == 3 else 0)
+    # optional [Conv2d(C, C, k, padding (k-1)/2), BN, ReLU] x num_conv_layers in front of the final conv
+    # (topdown_heatmap_simple_head.py:112-138); final_layer is then an nn.Sequential and its keys carry indices
+    nconv = extra.get('num_conv_layers', 0)
+    kernels = extra.get('num_conv_kernels', [1] * nconv)
+    for i in range(nconv):
+        x = F.conv2d(x, sd[f'final_layer.{3 * i}.weight'], sd[f'final_layer.{3 * i}.bias'], padding=(kernels[i] - 1) // 2)
+        bn = f'final_layer.{3 * i + 1}.'
+        x = F.batch_norm(x, sd[bn + 'running_mean'], sd[bn + 'running_var'],
+                         sd[bn + 'weight'], sd[bn + 'bias'], training, bn_momentum, 1e-5)
+        x = F.relu(x)
+    fl = f'final_layer.{3 * nconv}.' if nconv else 'final_layer.'
+    return F.conv2d(x, sd[fl + 'weight'], sd[fl + 'bias'], padding=1 if fk == 3 else 0)
 
 
 def joints_mse_loss(output: Tensor, target: Tensor, target_weight: Optional[Tensor],
@@ -375,10 +386,17 @@ def head_param_shapes(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
         out += [(bn + 'weight', (co,)), (bn + 'bias', (co,)),
                 (bn + 'running_mean', (co,)), (bn + 'running_var', (co,))]
         cin = co
-    fk = (cfg.get('extra') or {}).get('final_conv_kernel', 1)
+    extra = cfg.get('extra') or {}
+    fk = extra.get('final_conv_kernel', 1)
     if fk:
-        out += [('final_layer.weight', (cfg['out_channels'], cin, fk, fk)),
-                ('final_layer.bias', (cfg['out_channels'],))]
+        nconv = extra.get('num_conv_layers', 0)
+        kernels = extra.get('num_conv_kernels', [1] * nconv)
+        for i in range(nconv):
+            out += [(f'final_layer.{3 * i}.weight', (cin, cin, kernels[i], kernels[i])), (f'final_layer.{3 * i}.bias', (cin,))]
+            bn = f'final_layer.{3 * i + 1}.'
+            out += [(bn + 'weight', (cin,)), (bn + 'bias', (cin,)), (bn + 'running_mean', (cin,)), (bn + 'running_var', (cin,))]
+        fl = f'final_layer.{3 * nconv}.' if nconv else 'final_layer.'
+        out += [(fl + 'weight', (cfg['out_channels'], cin, fk, fk)), (fl + 'bias', (cfg['out_channels'],))]
     return out
 
 

@@ -312,6 +312,32 @@ def test_no_last_norm_train_step_and_exact_eval_vs_oracle(dev):
         assert meas(f'no last_norm grad {n}', relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0]) < 0.1, n
 
 
+def test_head_with_conv_layers_whole_model_train_step_vs_oracle(dev):
+    """The whole training step with `extra=dict(num_conv_layers=1, num_conv_kernels=(3,), final_conv_kernel=3)` on
+    the classic head (topdown_heatmap_simple_head.py:112-138): loss, heat maps, head and backbone gradients against
+    the oracle under torch autograd, then bf16 evaluation."""
+    hc = dict(O.classic_head_cfg(TOY['embed_dim']), extra=dict(final_conv_kernel=3, num_conv_layers=1, num_conv_kernels=(3,)))
+    bb, hd = O.synth_vit_weights(TOY, seed=21), O.synth_head_weights(hc, seed=22)
+    eng = make_engine(TOY, hc, bb, hd, dev)
+    img, target, tw = O.synth_batch(2, seed=23)
+    ref_eval = O.head_forward({k: v.clone() for k, v in hd.items()}, O.vit_forward(bb, img, TOY), hc, training=False)
+    got = eng.infer(img.to(dev))
+    assert meas('conv-layer head eval heat rel', relerr(got, ref_eval)[0]) < 2e-2
+    loss, heat = eng.forward_backward(img.to(dev), target.to(dev), tw.to(dev), drop_path=False)
+    torch.cuda.synchronize()
+    bbr = {k: v.clone().requires_grad_() for k, v in bb.items()}
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    ref = O.head_forward(hdr, O.vit_forward(bbr, img, TOY), hc, training=True)
+    rl = O.joints_mse_loss(ref, target, tw)
+    rl.backward()
+    assert meas('conv-layer head heat rel', relerr(heat, ref.detach())[0]) < 1.5e-2
+    assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
+    for n in ('final_layer.3.weight', 'final_layer.3.bias', 'final_layer.0.weight', 'final_layer.1.weight', 'deconv_layers.3.weight'):
+        assert meas(f'conv-layer head grad {n}', relerr(eng.store.gview('keypoint_head.' + n), hdr[n].grad)[0]) < 0.1, n
+    for n in ('blocks.1.mlp.fc2.weight', 'blocks.0.attn.qkv.weight', 'patch_embed.proj.weight'):
+        assert meas(f'conv-layer head grad {n}', relerr(eng.store.gview('backbone.' + n), bbr[n].grad)[0]) < 0.18, n
+
+
 @pytest.mark.parametrize('name', ['L', 'H'])
 def test_large_and_huge_widths_one_block_train_step(dev, name):
     """ViTPose-L / -H widths (E 1024 / 1280, head_dim 64 / 80) through one block + classic head,

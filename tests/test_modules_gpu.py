@@ -397,3 +397,58 @@ def test_topdown_ddp_overlapped_rccl_path_from_the_autograd_thread(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nl,convs,fk', [(2, (1,), 1), (2, (3, 1), 3), (0, (3,), 1), (2, (), 3), (0, (1, 3), 3)])
+def test_head_extra_conv_layers_and_3x3_final_conv_vs_oracle(dev, nl, convs, fk):
+    """`extra=dict(num_conv_layers, num_conv_kernels, final_conv_kernel)` of topdown_heatmap_simple_head.py:112-138:
+    [Conv2d(C, C, k), BatchNorm, ReLU] layers between the deconv stack and the final conv, and a 3 x 3 final conv
+    behind deconvs.  Forward, input gradient, every parameter gradient and the running statistics against the oracle,
+    then evaluation mode."""
+    from vitpose_amd.models import TopdownHeatmapSimpleHead
+    hc = dict(in_channels=64, out_channels=17, num_deconv_layers=nl, num_deconv_filters=(128, 64)[:nl],
+              num_deconv_kernels=(4, 4)[:nl], upsample=0,
+              extra=dict(final_conv_kernel=fk, num_conv_layers=len(convs), num_conv_kernels=convs))
+    head = TopdownHeatmapSimpleHead(loss_keypoint=dict(LOSS), **hc)
+    hd = O.synth_head_weights(hc, seed=4)
+    assert set(hd) >= {n for n, _ in head.named_parameters()}
+    head.load_state_dict(hd, strict=False)
+    head = head.to(dev).train()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 16, 12, generator=g)
+    Ho, Wo = 16 * 2 ** nl, 12 * 2 ** nl
+    target = torch.rand(2, 17, Ho, Wo, generator=g)
+    tw = (torch.rand(2, 17, 1, generator=g) > 0.2).float()
+    xd = x.to(dev).requires_grad_()
+    out = head(xd)
+    assert tuple(out.shape) == (2, 17, Ho, Wo)
+    head.get_loss(out, target.to(dev), tw.to(dev))['heatmap_loss'].backward()
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    xr = x.clone().requires_grad_()
+    ref = O.head_forward(hdr, xr, hc, training=True)
+    O.joints_mse_loss(ref, target, tw).backward()
+    tag = f'head nl{nl} convs{convs} fk{fk}'
+    assert meas(tag + ' heat rel', rel(out, ref)) < 2e-2
+    assert meas(tag + ' dx rel', rel(xd.grad, xr.grad)) < (0.12 if nl + len(convs) <= 3 else 0.2)
+    errs = {}
+    for n, p in head.named_parameters():
+        assert p.grad.shape == hdr[n].grad.shape
+        if convs and n.endswith('.bias') and n[:-4] + 'weight' in hdr and hdr[n[:-4] + 'weight'].dim() == 4 \
+                and not n.startswith(f'final_layer.{3 * len(convs)}.'):
+            # the bias of a conv in front of a batch-statistics BatchNorm has a zero gradient (the mean removes it)
+            assert float(p.grad.abs().max()) < 1e-2 * float(max(q.grad.abs().max() for q in head.parameters()))
+            continue
+        errs[n] = meas(tag + f' grad {n}', rel(p.grad, hdr[n].grad))
+    # every BatchNorm backward between the loss and a gradient subtracts batch means, which cancels most of the signal
+    # and amplifies the bf16 rounding of the maps: the bound grows with the depth of the stack
+    bound = 0.1 if nl + len(convs) <= 3 else 0.18
+    assert max(errs.values()) < bound, errs
+    sd1 = head.state_dict()
+    for n in hd:
+        if 'running' in n:
+            assert rel(sd1[n], hdr[n]) < 5e-3, n
+    head.eval()
+    with torch.no_grad():
+        out_e = head(x.to(dev))
+    ref_e = O.head_forward({k: v.cpu() for k, v in head.state_dict().items()}, x, hc, training=False)
+    assert meas(tag + ' eval heat rel', rel(out_e, ref_e)) < 2e-2

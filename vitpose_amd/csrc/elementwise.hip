@@ -377,6 +377,74 @@ extern "C" int vp_deconv_out_gather16(const void* dout, void* g, int B, int H, i
     VP_LAUNCH_RET();
 }
 
+// 3 x 3 convolution (stride 1, padding 1) on channels-last maps as a GEMM: col[(b, y, x)][t * C + c] =
+// in[b][y + ky - 1][x + kx - 1][c] with t = 3 ky + kx (zero outside the map), and its transpose for the data gradient:
+// din[(b, y, x)][c] = sum_t dcol[(b, y - ky + 1, x - kx + 1)][t * C + c] (f32 sum, optional ReLU mask of the layer input).
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16* __restrict__ in, bf16* __restrict__ col, int B, int H,
+                                                        int W, int C8) {
+    const size_t total = (size_t)B * H * W * 9 * C8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        const int t = (int)((i / C8) % 9);
+        const size_t pix = i / ((size_t)9 * C8);
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        const size_t b = pix / ((size_t)W * H);
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            v = *reinterpret_cast<const uint4*>(in + (((b * H + yy) * W + xx) * (size_t)C8 + c) * 8);
+        *reinterpret_cast<uint4*>(col + i * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const bf16* __restrict__ dcol, bf16* __restrict__ din,
+                                                        const bf16* __restrict__ relu_aux, int B, int H, int W, int C8) {
+    const size_t total = (size_t)B * H * W * C8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        const size_t pix = i / C8;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        const size_t b = pix / ((size_t)W * H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y - (t / 3) + 1, xx = x - (t % 3) + 1;      // the output pixel that read this one through tap t
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcol + ((((b * H + yy) * W + xx) * 9 + t) * (size_t)C8 + c) * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            }
+        }
+        bf16x8 o;
+        if (relu_aux) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(relu_aux + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] > 0.f ? acc[j] : 0.f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+        }
+        *reinterpret_cast<bf16x8*>(din + i * 8) = o;
+    }
+}
+
+extern "C" int vp_im2col3x3_bf16(const void* in, void* col, int B, int H, int W, int C, hipStream_t stream) {
+    VP_CHECK_ARG(in && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    VP_CHECK_ARG((((uintptr_t)in | (uintptr_t)col) & 15) == 0);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((size_t)B * H * W * 9 * (C / 8))), dim3(256), 0, stream,
+                       (const bf16*)in, (bf16*)col, B, H, W, C / 8);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_col2im3x3_bf16(const void* dcol, void* din, const void* relu_aux, int B, int H, int W, int C,
+                                 hipStream_t stream) {
+    VP_CHECK_ARG(dcol && din && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    VP_CHECK_ARG((((uintptr_t)dcol | (uintptr_t)din | (uintptr_t)relu_aux) & 15) == 0);
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for((size_t)B * H * W * (C / 8))), dim3(256), 0, stream,
+                       (const bf16*)dcol, (bf16*)din, (const bf16*)relu_aux, B, H, W, C / 8);
+    VP_LAUNCH_RET();
+}
+
 // A ConvTranspose2d(stride 2) weight with a 3 x 3 (padding 1, output_padding 1) or 2 x 2 (padding 0) kernel written
 // into the 4 x 4 kernel (padding 1) that computes the same layer: output pixel o receives input pixel i through tap
 // o - 2 i + 1 of a 4-tap kernel, through tap o - 2 i + 1 of the 3-tap one (its taps are taps 0..2 of the 4) and

@@ -36,10 +36,20 @@ def head_param_shapes(cfg) -> Tuple[List[Tuple[str, Tuple[int, ...]]], List[Tupl
         params += [(bn + 'weight', (co,)), (bn + 'bias', (co,))]
         bufs += [(bn + 'running_mean', (co,)), (bn + 'running_var', (co,))]
         cin = co
-    fk = (cfg.get('extra') or {}).get('final_conv_kernel', 1)
+    extra = cfg.get('extra') or {}
+    fk = extra.get('final_conv_kernel', 1)
     if fk:
-        params += [('final_layer.weight', (cfg['out_channels'], cin, fk, fk)),
-                   ('final_layer.bias', (cfg['out_channels'],))]
+        # optional [Conv2d, BN, ReLU] x num_conv_layers in front of the final conv: final_layer is an nn.Sequential then
+        nconv = extra.get('num_conv_layers', 0)
+        kernels = extra.get('num_conv_kernels', [1] * nconv)
+        for i in range(nconv):
+            params += [(f'final_layer.{3 * i}.weight', (cin, cin, kernels[i], kernels[i])),
+                       (f'final_layer.{3 * i}.bias', (cin,))]
+            bn = f'final_layer.{3 * i + 1}.'
+            params += [(bn + 'weight', (cin,)), (bn + 'bias', (cin,))]
+            bufs += [(bn + 'running_mean', (cin,)), (bn + 'running_var', (cin,))]
+        fl = f'final_layer.{3 * nconv}.' if nconv else 'final_layer.'
+        params += [(fl + 'weight', (cfg['out_channels'], cin, fk, fk)), (fl + 'bias', (cfg['out_channels'],))]
     return params, bufs
 
 
@@ -87,18 +97,22 @@ class HeadRunner:
         extra = cfg.get('extra') or {}
         self.fk = extra.get('final_conv_kernel', 1)
         self.upsample = cfg.get('upsample', 0)
-        if extra.get('num_conv_layers', 0):
-            raise NotImplementedError('extra conv layers in the head')
+        # optional [Conv2d(C, C, k), BN, ReLU] layers in front of the final conv (topdown_heatmap_simple_head.py:112-138)
+        self.nconv = int(extra.get('num_conv_layers', 0))
+        self.ck = [int(k) for k in extra.get('num_conv_kernels', [1] * self.nconv)][:self.nconv]
+        if any(k not in (1, 3) for k in self.ck) or len(self.ck) != self.nconv:
+            raise NotImplementedError('conv layers of the head: kernel size 1 or 3, one per layer')
+        self.fname = f'final_layer.{3 * self.nconv}.' if self.nconv else 'final_layer.'
         if self.nl:
             if any(k not in (2, 3, 4) for k in cfg['num_deconv_kernels'][:self.nl]):
                 raise ValueError(f"Not supported num_kernels ({cfg['num_deconv_kernels']}).")
-            if self.fk != 1 or self.upsample:
-                raise NotImplementedError('deconv head with final_conv_kernel != 1 or upsample')
+        if (self.nl or self.nconv) and self.upsample:
+            raise NotImplementedError('deconv / conv layers behind a bilinear upsample')
         if self.fk not in (1, 3):
             raise NotImplementedError('HIP head needs a final conv (final_conv_kernel 1 or 3)')
         self.kpad = (self.K + KPAD - 1) // KPAD * KPAD
         dev = store.device
-        self.simple = self.nl == 0 and (self.fk == 3 or self.upsample > 0)
+        self.simple = self.nl == 0 and self.nconv == 0 and (self.fk == 3 or self.upsample > 0)
         if self.simple:
             self._init_simple(dev)
             return
@@ -116,15 +130,25 @@ class HeadRunner:
         self.w4 = [torch.zeros(self.chans[l], self.chans[l + 1], 4, 4, dtype=torch.float32, device=dev)
                    if self.dk[l] != 4 else None for l in range(self.nl)]
         cl = self.chans[-1]
-        self.wf = torch.zeros(self.kpad, cl, dtype=torch.bfloat16, device=dev)
+        if cl % 64:
+            raise NotImplementedError('the head\'s conv channels must be a multiple of 64')
+        ft = self.fk * self.fk                         # taps of the final conv: its GEMM reduces over (tap, channel)
+        self.wf = torch.zeros(self.kpad, ft * cl, dtype=torch.bfloat16, device=dev)
         self.bf = torch.zeros(self.kpad, dtype=torch.float32, device=dev)
-        self.dwf = torch.zeros(self.kpad, cl, dtype=torch.float32, device=dev)
+        self.dwf = torch.zeros(self.kpad, ft * cl, dtype=torch.float32, device=dev)
         self.dbf = torch.zeros(self.kpad, dtype=torch.float32, device=dev)
-        self.bn_scale = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
-        self.bn_shift = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
-        self.bn_mean = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
-        self.bn_invstd = [torch.empty(c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
-        self.bn_sums = [torch.zeros(2 * c, dtype=torch.float32, device=dev) for c in self.chans[1:]]
+        # BatchNorm state: the deconv layers' first, then the conv layers'
+        bnc = self.chans[1:] + [cl] * self.nconv
+        self.bn_names = [f'deconv_layers.{3 * l + 1}.' for l in range(self.nl)] + \
+                        [f'final_layer.{3 * i + 1}.' for i in range(self.nconv)]
+        self.bn_scale = [torch.empty(c, dtype=torch.float32, device=dev) for c in bnc]
+        self.bn_shift = [torch.empty(c, dtype=torch.float32, device=dev) for c in bnc]
+        self.bn_mean = [torch.empty(c, dtype=torch.float32, device=dev) for c in bnc]
+        self.bn_invstd = [torch.empty(c, dtype=torch.float32, device=dev) for c in bnc]
+        self.bn_sums = [torch.zeros(2 * c, dtype=torch.float32, device=dev) for c in bnc]
+        # conv layers: weight as the GEMM operand [Cout][(tap, Cin)] (bf16) and its f32 gradient
+        self.wcv = [torch.zeros(cl, k * k * cl, dtype=torch.bfloat16, device=dev) for k in self.ck]
+        self.dwcv = [torch.zeros(cl, k * k * cl, dtype=torch.float32, device=dev) for k in self.ck]
 
     def _init_simple(self, dev):
         cfg = self.cfg
@@ -180,9 +204,14 @@ class HeadRunner:
                                         self.chans[l] * self.chans[l + 1], self.dk[l])
             # wph[phase][co][(ty,tx,ci)] = W[ci][co][(1-py)+2ty][(1-px)+2tx]; wd[ci][(ky,kx,co)] = W[ci][co][ky][kx]
             plan.deconv_weight_prep(self.deconv_w4(l), self.wph[l], self.wd[l], self.chans[l], self.chans[l + 1])
-        Wf = self.w('final_layer.weight')  # [K][C][1][1]
-        plan.strided_cast(Wf, self.wf, (1, 1, 1, Wf.numel()), (0, 0, 0, 1))
-        plan.strided_cast(self.w('final_layer.bias'), self.bf, (1, 1, 1, self.K), (0, 0, 0, 1))
+        cl = self.chans[-1]
+        for i, k in enumerate(self.ck):
+            # wcv[co][t * C + ci] = W[co][ci][tap t]
+            plan.strided_cast(self.w(f'final_layer.{3 * i}.weight'), self.wcv[i], (1, cl, k * k, cl), (0, cl * k * k, 1, k * k))
+        Wf = self.w(self.fname + 'weight')  # [K][C][fk][fk] -> wf[k][t * C + c]
+        ft = self.fk * self.fk
+        plan.strided_cast(Wf, self.wf, (1, self.K, ft, cl), (0, cl * ft, 1, ft))
+        plan.strided_cast(self.w(self.fname + 'bias'), self.bf, (1, 1, 1, self.K), (0, 0, 0, 1))
 
     # -- fp32-accurate evaluation: pair arrays of the compute-layout weights + the forward pass --
     def record_weight_prep_exact(self, plan: Plan):
@@ -198,6 +227,8 @@ class HeadRunner:
                                   (0, 0, self.cin * self.taps, self.taps))
             plan.split_pair(self._wcat32, self.wcat_pair, self._wcat32.numel())
             return
+        if self.nconv or self.fk != 1:
+            raise NotImplementedError('fp32-accurate evaluation of a head with conv layers or a 3 x 3 conv behind deconvs')
         self._wph32 = [f32(4, self.chans[l + 1], 4 * self.chans[l]) for l in range(self.nl)]
         self.wph_pair = [torch.zeros(4, self.chans[l + 1], 8 * self.chans[l], dtype=torch.bfloat16, device=dev)
                          for l in range(self.nl)]
@@ -310,8 +341,34 @@ class HeadRunner:
             H, W = 2 * H, 2 * W
         Mh = B * H * W
         cl = self.chans[-1]
+        for i, k in enumerate(self.ck):
+            # Conv2d(C, C, k, padding k // 2) + BatchNorm + ReLU on the output grid: a GEMM over (tap, channel)
+            j = self.nl + i
+            bn = self.bn_names[j]
+            x, kd = a, cl
+            if k == 3:
+                x, kd = ws.bf16('cv_col', Mh, 9 * cl), 9 * cl
+                plan.im2col3x3(a, x, B, H, W, cl)
+            z = ws.bf16(f'cz.{i}' if training else f'cz_{i}', Mh, cl)
+            plan.gemm(x, self.wcv[i], z, Mh, cl, kd, ldx=kd, ldy=kd, ldo=cl, bias=self.w(f'final_layer.{3 * i}.bias'))
+            if training and not running_stats:
+                plan.bn_stats(z, self.bn_sums[j], Mh, cl)
+            plan.bn_finalize(self.bn_sums[j] if training and not running_stats else None, Mh, cl,
+                             self.w(bn + 'weight'), self.w(bn + 'bias'),
+                             self.buf(bn + 'running_mean'), self.buf(bn + 'running_var'), 0.1, 1e-5,
+                             self.bn_scale[j], self.bn_shift[j],
+                             self.bn_mean[j] if training else None, self.bn_invstd[j] if training else None)
+            act = ws.bf16(f'ca.{i}', Mh, cl) if training else z
+            plan.bn_apply_relu(z, act, self.bn_scale[j], self.bn_shift[j], Mh, cl)
+            a = act
         heat = ws.f32('heat_cl', Mh, self.kpad)
-        plan.gemm(a, self.wf, heat, Mh, self.kpad, cl, ldx=cl, ldy=cl, ldo=self.kpad, epilogue=_lib.VP_EPI_F32, bias=self.bf)
+        if self.fk == 3:
+            col = ws.bf16('cv_col', Mh, 9 * cl)
+            plan.im2col3x3(a, col, B, H, W, cl)
+            plan.gemm(col, self.wf, heat, Mh, self.kpad, 9 * cl, ldx=9 * cl, ldy=9 * cl, ldo=self.kpad,
+                      epilogue=_lib.VP_EPI_F32, bias=self.bf)
+        else:
+            plan.gemm(a, self.wf, heat, Mh, self.kpad, cl, ldx=cl, ldy=cl, ldo=self.kpad, epilogue=_lib.VP_EPI_F32, bias=self.bf)
         dheat = ws.bf16('dheat', Mh, self.kpad) if want_grad else None
         plan.heatmap_loss(heat, self.kpad, heat_nchw, target, tw, loss, dheat, B, self.K, H * W, loss_weight)
         self._last_act = a
@@ -377,24 +434,61 @@ class HeadRunner:
         H, W = self.out_hw
         Mh = B * H * W
         cl = self.chans[-1]
-        a_last = ws.bufs[f'a.{self.nl - 1}'] if self.nl else feat
-        # final 1x1 conv
-        slab = ws.f32('splitk_slab_head', _slab_elems(max(self.chans[l] * 16 * self.chans[l + 1]
-                                                          for l in range(self.nl)) if self.nl else self.kpad * cl, Mh))
+        def act_in(i):
+            """(input of conv layer i -- i == nconv: of the final conv --, whether it is the output of a ReLU)"""
+            if i > 0:
+                return ws.bufs[f'ca.{i - 1}'], True
+            return (ws.bufs[f'a.{self.nl - 1}'], True) if self.nl else (feat, False)
+        a_last, relu_last = act_in(self.nconv)
+        ft = self.fk * self.fk
+        slab = ws.f32('splitk_slab_head', _slab_elems(max([self.chans[l] * 16 * self.chans[l + 1] for l in range(self.nl)] +
+                                                          [cl * k * k * cl for k in self.ck] + [self.kpad * ft * cl]), Mh))
         # vp_colsum_bf16 and vp_bn_bwd accumulate: their targets start from zero (one launch)
-        plan.zero_small([self.dbf] + [self.g(f'deconv_layers.{3 * l + 1}.{k}') for l in range(self.nl) for k in ('weight', 'bias')])
-        plan.wgrad(dheat, a_last, self.dwf, self.kpad, cl, Mh, ldx=self.kpad, ldy=cl, split_k=_split_k(self.kpad, cl, Mh), slab=slab)
+        plan.zero_small([self.dbf] + [self.g(n + k) for n in self.bn_names for k in ('weight', 'bias')] +
+                        [self.g(f'final_layer.{3 * i}.bias') for i in range(self.nconv)])
+
+        def conv_bwd(dy, ldy_, nout, wmat, dwmat, k, x_in, relu_in, tag):
+            """Backward of y = conv_k(x_in) as a GEMM over (tap, channel): the weight gradient into dwmat [nout][k*k*cl]
+            and the gradient wrt x_in (times the ReLU mask when x_in is a ReLU's output)."""
+            kd = k * k * cl
+            if k == 3:
+                col = ws.bf16('cv_col', Mh, kd)
+                plan.im2col3x3(x_in, col, B, H, W, cl)
+            else:
+                col = x_in
+            plan.wgrad(dy, col, dwmat, nout, kd, Mh, ldx=ldy_, ldy=kd, split_k=_split_k(nout, kd, Mh), slab=slab)
+            gin = ws.bf16('hg' + tag, Mh, cl)
+            if k == 3:
+                dcol = ws.bf16('cv_col', Mh, kd)           # the im2col rows are dead once the weight gradient has run
+                plan.gemm(dy, wmat, dcol, Mh, kd, nout, ldx=ldy_, ldy=kd, ldo=kd, y_kmajor=True)
+                plan.col2im3x3(dcol, gin, B, H, W, cl, relu_aux=x_in if relu_in else None)
+            elif relu_in:
+                plan.gemm(dy, wmat, gin, Mh, cl, nout, ldx=ldy_, ldy=cl, ldo=cl, y_kmajor=True,
+                          epilogue=_lib.VP_EPI_DRELU, aux=x_in, ldaux=cl)
+            else:
+                plan.gemm(dy, wmat, gin, Mh, cl, nout, ldx=ldy_, ldy=cl, ldo=cl, y_kmajor=True)
+            return gin
+
+        # final conv
         plan.colsum(dheat, self.dbf, Mh, self.kpad, self.kpad)
+        g = conv_bwd(dheat, self.kpad, self.kpad, self.wf, self.dwf, self.fk, a_last, relu_last, '')
         # the first K rows of the padded gradients are the final layer's (stored: no zeroed gradient buffer needed)
-        gW, gb, K = self.g('final_layer.weight'), self.g('final_layer.bias'), self.K
-        plan.strided_cast(self.dwf, gW, (1, 1, 1, gW.numel()), (0, 0, 0, 1))
+        gW, gb, K = self.g(self.fname + 'weight'), self.g(self.fname + 'bias'), self.K
+        plan.strided_cast(self.dwf, gW, (K, cl, ft, 1), (ft * cl, 1, cl, 0))
         plan.strided_cast(self.dbf, gb, (1, 1, 1, K), (0, 0, 0, 1))
-        g = ws.bf16('hg', Mh, cl)
+        for i in range(self.nconv - 1, -1, -1):
+            j, k = self.nl + i, self.ck[i]
+            bn = self.bn_names[j]
+            dz = ws.bf16('hdz', Mh, cl)
+            plan.bn_bwd(g, ws.bufs[f'cz.{i}'], self.bn_mean[j], self.bn_invstd[j], self.w(bn + 'weight'),
+                        self.g(bn + 'weight'), self.g(bn + 'bias'), dz, Mh, cl, running_stats=running_stats)
+            plan.colsum(dz, self.g(f'final_layer.{3 * i}.bias'), Mh, cl, cl)
+            x_in, relu_in = act_in(i)
+            g = conv_bwd(dz, cl, cl, self.wcv[i], self.dwcv[i], k, x_in, relu_in, '_c' if i % 2 else '_c2')
+            # [co][(tap, ci)] -> the parameter's [co][ci][tap] (stored)
+            plan.strided_cast(self.dwcv[i], self.g(f'final_layer.{3 * i}.weight'), (cl, cl, k * k, 1), (k * k * cl, 1, cl, 0))
         if self.nl == 0:
-            plan.gemm(dheat, self.wf, g, Mh, cl, self.kpad, ldx=self.kpad, ldy=cl, ldo=cl, y_kmajor=True)
             return g
-        plan.gemm(dheat, self.wf, g, Mh, cl, self.kpad, ldx=self.kpad, ldy=cl, ldo=cl, y_kmajor=True,
-                  epilogue=_lib.VP_EPI_DRELU, aux=a_last, ldaux=cl)
         for l in range(self.nl - 1, -1, -1):
             ci, co = self.chans[l], self.chans[l + 1]
             Hi, Wi = H // 2, W // 2

@@ -472,6 +472,14 @@ class Plan:
         _chk(w, torch.float32, 'w')
         self._add('vp_deconv_weight_prep', _p(w), _p(wph), _p(wd), Ci, Co, keep=(w, wph, wd))
 
+    def im2col3x3(self, src, col, B, H, W, C):
+        _chk(src, torch.bfloat16, 'src'), _chk(col, torch.bfloat16, 'col')
+        self._add('vp_im2col3x3_bf16', _p(src), _p(col), B, H, W, C, keep=(src, col))
+
+    def col2im3x3(self, dcol, din, B, H, W, C, relu_aux=None):
+        _chk(dcol, torch.bfloat16, 'dcol'), _chk(din, torch.bfloat16, 'din'), _chk(relu_aux, torch.bfloat16, 'relu_aux')
+        self._add('vp_col2im3x3_bf16', _p(dcol), _p(din), _p(relu_aux), B, H, W, C, keep=(dcol, din, relu_aux))
+
     def deconv_weight_pad4(self, w, w4, n, k):
         """w [n][k][k] (k 2 or 3) -> the equivalent 4 x 4 kernel w4 [n][4][4] (f32)."""
         _chk(w, torch.float32, 'w'), _chk(w4, torch.float32, 'w4')
