@@ -854,3 +854,24 @@ def test_deconv_weight_prep_layouts(dev, Ci, Co):
         for px in range(2):
             want = wb[:, :, (1 - py)::2, (1 - px)::2]                  # [ci][co][ty][tx]
             assert torch.equal(wph[py * 2 + px].view(Co, 2, 2, Ci), want.permute(1, 2, 3, 0))
+
+
+@pytest.mark.parametrize('B,H,W,C', [(2, 16, 12, 64), (1, 5, 7, 8), (3, 64, 48, 256)])
+def test_im2col3x3_and_col2im3x3_bit_exact(dev, B, H, W, C):
+    """3 x 3 / stride 1 / padding 1 conv as a GEMM: the column matrix [(b, y, x)][(ky, kx, c)] against F.unfold (bit-exact
+    copy) and its adjoint against F.fold on small integers (exact in bf16), with and without the ReLU mask."""
+    x = ints((B, C, H, W), dev, -3, 4, seed=1)
+    xcl = x.permute(0, 2, 3, 1).contiguous().bfloat16().view(B * H * W, C)
+    col = torch.full((B * H * W, 9 * C), float('nan'), device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.im2col3x3(xcl, col, B, H, W, C))
+    # unfold orders a column (c, ky, kx); the kernel's is (ky, kx, c)
+    ref = torch.nn.functional.unfold(x, 3, padding=1).view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * C)
+    assert torch.equal(col.float(), ref)
+    d = ints((B * H * W, 9 * C), dev, -2, 3, seed=2).bfloat16()
+    din = torch.full((B * H * W, C), float('nan'), device=dev, dtype=torch.bfloat16)
+    dm = torch.full_like(din, float('nan'))
+    run(lambda p: (p.col2im3x3(d, din, B, H, W, C), p.col2im3x3(d, dm, B, H, W, C, relu_aux=xcl)))
+    fold_in = d.float().view(B, H * W, 9, C).permute(0, 3, 2, 1).reshape(B, C * 9, H * W)
+    want = torch.nn.functional.fold(fold_in, (H, W), 3, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, C)
+    assert torch.equal(din.float(), want)
+    assert torch.equal(dm.float(), want * (xcl.float() > 0))
