@@ -279,6 +279,16 @@ int vp_deconv_weight_prep(const float* w, void* wph_bf16, void* wd_bf16, int Ci,
 int vp_im2col3x3_bf16(const void* in_bf16, void* col_bf16, int B, int H, int W, int C, vp_stream_t stream);
 int vp_col2im3x3_bf16(const void* dcol_bf16, void* din_bf16, const void* relu_aux_bf16, int B, int H, int W, int C,
                       vp_stream_t stream);
+/* input_transform='resize_concat' (topdown_heatmap_simple_head.py:289-298: every selected feature map bilinearly resized
+ * to the first one's size, then concatenated along the channels): one NCHW f32 map [B][C][Hi][Wi] resized to Ho x Wo into
+ * the columns [coff, coff + C) of the channels-last bf16 matrix dst [B*Ho*Wo][ld].  yi/yw [Ho][2], xi/xw [Wo][2] are
+ * the source index pairs and weights of F.interpolate(mode='bilinear', align_corners) per output coordinate.  The
+ * backward entry gathers the gradient g [B*Ho*Wo][ld] back: tyi/tyw [Hi][Ly], txi/txw [Wi][Lx] list, per source
+ * coordinate, the output coordinates that read it and their weights (index -1 = unused).  C, coff, ld multiples of 8. */
+int vp_resize_to_cl_bf16(const float* src, void* dst_bf16, const int* yi, const float* yw, const int* xi, const float* xw,
+                         int B, int C, int Hi, int Wi, int Ho, int Wo, int ld, int coff, vp_stream_t stream);
+int vp_resize_to_cl_bwd(const void* g_bf16, float* dx, const int* tyi, const float* tyw, const int* txi, const float* txw,
+                        int Ly, int Lx, int B, int C, int Hi, int Wi, int Ho, int Wo, int ld, int coff, vp_stream_t stream);
 /* The other two kernel sizes the head accepts (topdown_heatmap_base_head.py:105-120: kernel 3 -> padding 1,
  * output_padding 1; kernel 2 -> padding 0): w [n][k][k] f32 (n = Ci * Co) embedded in w4 [n][4][4] f32, the 4 x 4
  * kernel with padding 1 that computes the same transposed convolution (k = 3: taps 0..2, k = 2: taps 1..2 of each

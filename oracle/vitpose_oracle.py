@@ -193,6 +193,14 @@ def deconv_cfg(k: int) -> Tuple[int, int, int]:
     raise ValueError(f'Not supported num_kernels ({k}).')
 
 
+def head_resize_concat(inputs: Sequence[Tensor], in_index: Sequence[int], align_corners: bool = False) -> Tensor:
+    """topdown_heatmap_simple_head.py:289-298 (input_transform='resize_concat'): the selected maps, each resized
+    bilinearly to the first one's size (mmpose/models/utils/ops.py:7-29 -> F.interpolate), joined along the channels."""
+    xs = [inputs[i] for i in in_index]
+    size = xs[0].shape[2:]
+    return torch.cat([F.interpolate(x, size=size, mode='bilinear', align_corners=align_corners) for x in xs], dim=1)
+
+
 def head_forward(sd: Dict[str, Tensor], feat: Tensor, cfg: dict, training: bool = False,
                  bn_momentum: float = 0.1, taps: Optional[dict] = None) -> Tensor:
     """topdown_heatmap_simple_head.py:197-202 (+ :269-287, :306-337):

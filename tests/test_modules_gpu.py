@@ -452,3 +452,49 @@ def test_head_extra_conv_layers_and_3x3_final_conv_vs_oracle(dev, nl, convs, fk)
         out_e = head(x.to(dev))
     ref_e = O.head_forward({k: v.cpu() for k, v in head.state_dict().items()}, x, hc, training=False)
     assert meas(tag + ' eval heat rel', rel(out_e, ref_e)) < 2e-2
+
+
+@pytest.mark.parametrize('align_corners', [False, True])
+def test_head_resize_concat_inputs_vs_oracle(dev, align_corners):
+    """input_transform='resize_concat' (topdown_heatmap_simple_head.py:289-298): three maps of different sizes, selected
+    by in_index, resized to the first one's grid and joined; forward, the gradient of every input map and the parameter
+    gradients against the oracle (F.interpolate + cat in front of the oracle's head)."""
+    from vitpose_amd.models import TopdownHeatmapSimpleHead
+    kw = dict(in_channels=(64, 32, 32), in_index=(2, 0, 1), input_transform='resize_concat', align_corners=align_corners,
+              out_channels=17, num_deconv_layers=2, num_deconv_filters=(128, 64), num_deconv_kernels=(4, 4),
+              extra=dict(final_conv_kernel=1))
+    head = TopdownHeatmapSimpleHead(loss_keypoint=dict(LOSS), **kw)
+    hc = dict(in_channels=128, out_channels=17, num_deconv_layers=2, num_deconv_filters=(128, 64),
+              num_deconv_kernels=(4, 4), extra=dict(final_conv_kernel=1), upsample=0)
+    hd = O.synth_head_weights(hc, seed=5)
+    head.load_state_dict(hd, strict=False)
+    head = head.to(dev).train()
+    g = torch.Generator().manual_seed(12)
+    # backbone outputs 0, 1, 2; in_index picks (2, 0, 1): 64 ch at 16 x 12 first, then 32 ch at 8 x 6 and 32 ch at 24 x 20
+    feats = [torch.randn(2, 32, 8, 6, generator=g), torch.randn(2, 32, 24, 20, generator=g), torch.randn(2, 64, 16, 12, generator=g)]
+    target = torch.rand(2, 17, 64, 48, generator=g)
+    tw = (torch.rand(2, 17, 1, generator=g) > 0.2).float()
+    fd = [f.to(dev).requires_grad_() for f in feats]
+    out = head(fd)
+    assert tuple(out.shape) == (2, 17, 64, 48)
+    head.get_loss(out, target.to(dev), tw.to(dev))['heatmap_loss'].backward()
+    hdr = {k: (v.clone().requires_grad_() if 'running' not in k else v.clone()) for k, v in hd.items()}
+    fr = [f.clone().requires_grad_() for f in feats]
+    ref = O.head_forward(hdr, O.head_resize_concat(fr, kw['in_index'], align_corners), hc, training=True)
+    O.joints_mse_loss(ref, target, tw).backward()
+    assert meas(f'resize_concat ac{align_corners} heat rel', rel(out, ref)) < 2e-2
+    for i in range(3):
+        assert fd[i].grad.shape == fr[i].grad.shape
+        assert meas(f'resize_concat ac{align_corners} dx{i} rel', rel(fd[i].grad, fr[i].grad)) < 0.12
+    for n, p in head.named_parameters():
+        assert meas(f'resize_concat ac{align_corners} grad {n}', rel(p.grad, hdr[n].grad)) < 0.1, n
+    head.eval()
+    with torch.no_grad():
+        out_e = head([f.to(dev) for f in feats])
+    ref_e = O.head_forward({k: v.cpu() for k, v in head.state_dict().items()}, O.head_resize_concat(feats, kw['in_index'], align_corners),
+                           hc, training=False)
+    assert meas(f'resize_concat ac{align_corners} eval heat rel', rel(out_e, ref_e)) < 2e-2
+    # 'multiple_select' hands a list on to the layers: neither the reference head nor this one can execute it
+    head.input_transform = 'multiple_select'
+    with pytest.raises(NotImplementedError):
+        head([f.to(dev) for f in feats])

@@ -82,6 +82,8 @@ SIGNATURES = {
     'vp_bn_bwd': [P, P, P, P, P, P, P, P, c_int, c_int, P],
     'vp_im2col3x3_bf16': [P, P, c_int, c_int, c_int, c_int, P],
     'vp_col2im3x3_bf16': [P, P, P, c_int, c_int, c_int, c_int, P],
+    'vp_resize_to_cl_bf16': [P, P, P, P, P, P] + [c_int] * 8 + [P],
+    'vp_resize_to_cl_bwd': [P, P, P, P, P, P] + [c_int] * 10 + [P],
     'vp_deconv_weight_pad4': [P, P, c_size_t, c_int, P],
     'vp_bn_bwd_eval': [P, P, P, P, P, P, P, P, c_int, c_int, P],
     'vp_upconv_fwd': [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

@@ -148,7 +148,85 @@ __global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float* __restrict
     }
 }
 
+// 'resize_concat' input bridge: one NCHW f32 map [B][C][Hi][Wi], bilinearly resized to Ho x Wo, into the columns
+// [coff, coff + C) of the channels-last bf16 matrix [B*Ho*Wo][ld].  yi/yw [Ho][2], xi/xw [Wo][2]: source index pairs
+// and weights per output coordinate.  One thread per (b, 8-channel chunk, output pixel), pixel fastest.
+__global__ __launch_bounds__(256) void resize_to_cl_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                           const int* __restrict__ yi, const float* __restrict__ yw,
+                                                           const int* __restrict__ xi, const float* __restrict__ xw,
+                                                           int B, int C, int Hi, int Wi, int Ho, int Wo, int ld, int coff) {
+    const int chunks = C >> 3, HWo = Ho * Wo;
+    const size_t total = (size_t)B * chunks * HWo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HWo), ch = (int)((i / HWo) % chunks), b = (int)(i / ((size_t)HWo * chunks));
+        const int y = p / Wo, x = p % Wo;
+        const int y0 = yi[2 * y], y1 = yi[2 * y + 1], x0 = xi[2 * x], x1 = xi[2 * x + 1];
+        const float w00 = yw[2 * y] * xw[2 * x], w01 = yw[2 * y] * xw[2 * x + 1];
+        const float w10 = yw[2 * y + 1] * xw[2 * x], w11 = yw[2 * y + 1] * xw[2 * x + 1];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* s = src + ((size_t)b * C + ch * 8 + j) * Hi * Wi;
+            o[j] = (bf16)(w00 * s[y0 * Wi + x0] + w01 * s[y0 * Wi + x1] + w10 * s[y1 * Wi + x0] + w11 * s[y1 * Wi + x1]);
+        }
+        *reinterpret_cast<bf16x8*>(dst + ((size_t)b * HWo + p) * ld + coff + ch * 8) = o;
+    }
+}
+
+// Its transpose: dx[b][c][j][i] = sum over the output pixels (u, v) that interpolate from (j, i) of
+// wy * wx * g[(b, u, v)][coff + c].  tyi/tyw [Hi][Ly], txi/txw [Wi][Lx] list those pixels (-1 = unused slot).
+// One thread per (b, 8-channel chunk, source pixel), pixel fastest: the eight plane stores coalesce.
+__global__ __launch_bounds__(256) void resize_to_cl_bwd_kernel(const bf16* __restrict__ g, float* __restrict__ dx,
+                                                               const int* __restrict__ tyi, const float* __restrict__ tyw,
+                                                               const int* __restrict__ txi, const float* __restrict__ txw,
+                                                               int Ly, int Lx, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                                               int ld, int coff) {
+    const int chunks = C >> 3, HWi = Hi * Wi;
+    const size_t total = (size_t)B * chunks * HWi;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(t % HWi), ch = (int)((t / HWi) % chunks), b = (int)(t / ((size_t)HWi * chunks));
+        const int j = p / Wi, i = p % Wi;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < Ly; ++a) {
+            const int u = tyi[j * Ly + a];
+            if (u < 0) continue;
+            for (int c = 0; c < Lx; ++c) {
+                const int v = txi[i * Lx + c];
+                if (v < 0) continue;
+                const float w = tyw[j * Ly + a] * txw[i * Lx + c];
+                const bf16x8 q = *reinterpret_cast<const bf16x8*>(g + ((size_t)(b * Ho + u) * Wo + v) * ld + coff + ch * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += w * (float)q[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dx[((size_t)b * C + ch * 8 + k) * HWi + p] = acc[k];
+    }
+}
+
 }  // namespace
+
+extern "C" int vp_resize_to_cl_bf16(const float* src, void* dst, const int* yi, const float* yw, const int* xi,
+                                    const float* xw, int B, int C, int Hi, int Wi, int Ho, int Wo, int ld, int coff,
+                                    hipStream_t stream) {
+    VP_CHECK_ARG(src && dst && yi && yw && xi && xw && B > 0 && C > 0 && C % 8 == 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+    VP_CHECK_ARG(coff >= 0 && coff % 8 == 0 && ld % 8 == 0 && coff + C <= ld);
+    const size_t total = (size_t)B * (C / 8) * Ho * Wo;
+    hipLaunchKernelGGL(resize_to_cl_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src, (bf16*)dst, yi, yw, xi, xw, B,
+                       C, Hi, Wi, Ho, Wo, ld, coff);
+    VP_LAUNCH_RET();
+}
+
+extern "C" int vp_resize_to_cl_bwd(const void* g, float* dx, const int* tyi, const float* tyw, const int* txi,
+                                   const float* txw, int Ly, int Lx, int B, int C, int Hi, int Wi, int Ho, int Wo, int ld,
+                                   int coff, hipStream_t stream) {
+    VP_CHECK_ARG(g && dx && tyi && tyw && txi && txw && Ly > 0 && Lx > 0 && B > 0 && C > 0 && C % 8 == 0);
+    VP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && coff >= 0 && coff % 8 == 0 && ld % 8 == 0 && coff + C <= ld);
+    const size_t total = (size_t)B * (C / 8) * Hi * Wi;
+    hipLaunchKernelGGL(resize_to_cl_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16*)g, dx, tyi, tyw,
+                       txi, txw, Ly, Lx, B, C, Hi, Wi, Ho, Wo, ld, coff);
+    VP_LAUNCH_RET();
+}
 
 extern "C" int vp_upconv_fwd(const float* G, int ldg, const float* bias, float* out, const int* yi, const float* yw,
                              const int* xi, const float* xw, int B, int K, int kpad, int Hg, int Wg, int Ho, int Wo,

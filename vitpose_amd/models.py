@@ -31,7 +31,7 @@ import torch.nn as nn
 from . import _lib
 from .builder import BACKBONES, HEADS, LOSSES, POSENETS, build_backbone, build_head, build_loss, build_neck
 from .engine import ParamStore, VitRunner, Workspace
-from .head_engine import KPAD, HeadRunner
+from .head_engine import KPAD, HeadRunner, bilinear_tables
 from .plan import Plan
 
 
@@ -653,15 +653,18 @@ def pose_pck_accuracy_device(output, target, mask, thr=0.05):
 
 
 class _HeadFunction(torch.autograd.Function):
+    """nx feature maps (one, or the maps 'resize_concat' joins), then the parameters."""
+
     @staticmethod
-    def forward(ctx, mod, x, *params):
-        ctx.mod, ctx.shape = mod, tuple(x.shape)
-        return mod._run(x, keep=True)
+    def forward(ctx, mod, nx, *args):
+        xs = args[:nx]
+        ctx.mod, ctx.shapes = mod, tuple(tuple(x.shape) for x in xs)
+        return mod._run(xs, keep=True)
 
     @staticmethod
     def backward(ctx, dheat):
-        dx = ctx.mod._run_backward(dheat, ctx.shape)
-        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+        dxs = ctx.mod._run_backward(dheat, ctx.shapes)
+        return (None, None) + tuple(dxs) + (None,) * (len(ctx.needs_input_grad) - 2 - len(dxs))
 
 
 @HEADS.register_module()
@@ -832,8 +835,14 @@ class TopdownHeatmapSimpleHead(_FlatBound):
         the HIP plan; feature lists select `in_index`)."""
         if not isinstance(inputs, list):
             return inputs
-        if self.input_transform is not None:
-            raise NotImplementedError('resize_concat / multiple_select inputs are outside the HIP path')
+        if self.input_transform == 'resize_concat':
+            # the maps are resized and joined inside the HIP plan (vp_resize_to_cl_bf16 writes each one into its
+            # channel range of the channels-last matrix)
+            return [inputs[i] for i in self.in_index]
+        if self.input_transform == 'multiple_select':
+            # the reference hands the list on to nn.Sequential (topdown_heatmap_simple_head.py:199-201, :299-300),
+            # which cannot take one: the option is not executable with this head there either
+            raise NotImplementedError("input_transform='multiple_select': this head has a single input")
         return inputs[self.in_index]
 
     # BatchNorm2d.num_batches_tracked (a LongTensor buffer the reference's modules increment every training
@@ -872,19 +881,39 @@ class TopdownHeatmapSimpleHead(_FlatBound):
             self._seen_version = None
         return r
 
-    def _plan(self, shape, keep):
-        B, C, H, W = shape
-        key = (shape, keep, self.training)
+    def _resize_tabs(self, src_hw, dst_hw):
+        """Device tables of the bilinear resize src_hw -> dst_hw (ops.py:7-29 with `size=`): (forward, transposed)."""
+        key = ('rtab', src_hw, dst_hw)
+        if key not in self._runners:
+            dev = self._store.device
+            ty = bilinear_tables(src_hw[0], dst_hw[0], None, bool(self.align_corners))
+            tx = bilinear_tables(src_hw[1], dst_hw[1], None, bool(self.align_corners))
+            self._runners[key] = (tuple(t.reshape(-1).contiguous().to(dev) for t in (ty[0], ty[1], tx[0], tx[1])),
+                                  tuple(t.contiguous().to(dev) for t in (ty[2], ty[3], tx[2], tx[3])))
+        return self._runners[key]
+
+    def _plan(self, shapes, keep):
+        """shapes: the NCHW shape of every input map (one, or the maps 'resize_concat' resizes to the first one's
+        grid and joins along the channels)."""
+        B, _, H, W = shapes[0]
+        C = sum(s[1] for s in shapes)
+        key = (shapes, keep, self.training)
         if key not in self._plans:
             hr = self._runner((H, W))
             ws = self._runners.setdefault(('ws', keep), Workspace(self._store.device))
-            io = dict(x=ws.f32('x_nchw', B, C, H, W), feat=ws.bf16('feat_cl', B * H * W, C),
+            io = dict(xs=[ws.f32(f'x_nchw{i}', *s) for i, s in enumerate(shapes)], feat=ws.bf16('feat_cl', B * H * W, C),
                       heat=ws.f32('heat', B, hr.K, *hr.out_grid))
             fwd = Plan()
-            fwd.nchw_to_cl(io['x'], io['feat'], B, C, H * W, C)
+            if len(shapes) == 1:
+                fwd.nchw_to_cl(io['xs'][0], io['feat'], B, C, H * W, C)
+            else:
+                coff = 0
+                for x, s in zip(io['xs'], shapes):
+                    fwd.resize_to_cl(x, io['feat'], self._resize_tabs(s[2:], (H, W))[0], B, s[1], s[2], s[3], H, W, C, coff)
+                    coff += s[1]
             # eval mode with a gradient wanted: the deconv stack keeps its intermediates as in training, but its
             # BatchNorms normalise with (and do not update) the running statistics
-            frozen_bn = keep and not self.training and hr.nl > 0 and not hr.simple
+            frozen_bn = keep and not self.training and not hr.simple and hr.nl + hr.nconv > 0
             if frozen_bn:
                 hr.record_forward(fwd, ws, io['feat'], B, True, io['heat'], running_stats=True)
             else:
@@ -892,10 +921,16 @@ class TopdownHeatmapSimpleHead(_FlatBound):
             bwd = None
             if keep:
                 io['dheat'] = ws.f32('dheat_in', B, hr.K, *hr.out_grid)
-                io['dx'] = ws.f32('dx_nchw', B, C, H, W)
+                io['dxs'] = [ws.f32(f'dx_nchw{i}', *s) for i, s in enumerate(shapes)]
                 bwd = Plan()
                 g = hr.record_backward_nchw(bwd, ws, io['feat'], io['dheat'], B, running_stats=frozen_bn)
-                bwd.strided_cast(g, io['dx'], (B, C, H * W, 1), (H * W * C, 1, C, 0))
+                if len(shapes) == 1:
+                    bwd.strided_cast(g, io['dxs'][0], (B, C, H * W, 1), (H * W * C, 1, C, 0))
+                else:
+                    coff = 0
+                    for dx, s in zip(io['dxs'], shapes):
+                        bwd.resize_to_cl_bwd(g, dx, self._resize_tabs(s[2:], (H, W))[1], B, s[1], s[2], s[3], H, W, C, coff)
+                        coff += s[1]
             self._plans[key] = (fwd, bwd, io)
         return self._plans[key]
 
@@ -906,35 +941,40 @@ class TopdownHeatmapSimpleHead(_FlatBound):
             self._runners[('prep', grid)].run()
             self._seen_version = v
 
-    def _run(self, x, keep):
-        shape = tuple(x.shape)
-        if shape[1] != self._cfg['in_channels']:
-            raise ValueError(f'expected {self._cfg["in_channels"]} input channels, got {shape[1]}')
-        self._refresh(shape[2:])
-        fwd, _, io = self._plan(shape, keep)
-        io['x'].copy_(x)
+    def _run(self, xs, keep):
+        shapes = tuple(tuple(x.shape) for x in xs)
+        if sum(s[1] for s in shapes) != self._cfg['in_channels']:
+            raise ValueError(f'expected {self._cfg["in_channels"]} input channels, got {[s[1] for s in shapes]}')
+        if any(s[0] != shapes[0][0] or s[1] % 8 for s in shapes[1:]):
+            raise ValueError(f'resize_concat inputs need one batch size and channel counts in multiples of 8: {shapes}')
+        self._refresh(shapes[0][2:])
+        fwd, _, io = self._plan(shapes, keep)
+        for buf, x in zip(io['xs'], xs):
+            buf.copy_(x)
         fwd.run()
         if keep and self.training:
             self._bn_steps_pending += 1
         return io['heat'].clone()
 
-    def _run_backward(self, dheat, shape):
-        _, bwd, io = self._plan(shape, True)
+    def _run_backward(self, dheat, shapes):
+        _, bwd, io = self._plan(shapes, True)
         stash = self._stash_live_grads()
         io['dheat'].copy_(dheat)
         bwd.run()
         self._publish_grads(stash)
-        return io['dx'].clone()
+        return [dx.clone() for dx in io['dxs']]
 
     def forward(self, x):
         x = self._transform_inputs(x)
-        _need_hip(x, 'TopdownHeatmapSimpleHead.forward')
+        xs = [t.float() for t in x] if isinstance(x, list) else [x.float()]
+        for t in xs:
+            _need_hip(t, 'TopdownHeatmapSimpleHead.forward')
         if self._store is None:
             raise RuntimeError('move the module to the HIP device first (model.cuda())')
         params = list(self.parameters())
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-            return _HeadFunction.apply(self, x.float(), *params)
-        return self._run(x.float(), keep=False)
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in xs) or any(p.requires_grad for p in params)):
+            return _HeadFunction.apply(self, len(xs), *xs, *params)
+        return self._run(xs, keep=False)
 
 
 # =====================================================================================

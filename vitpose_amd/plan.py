@@ -480,6 +480,18 @@ class Plan:
         _chk(dcol, torch.bfloat16, 'dcol'), _chk(din, torch.bfloat16, 'din'), _chk(relu_aux, torch.bfloat16, 'relu_aux')
         self._add('vp_col2im3x3_bf16', _p(dcol), _p(din), _p(relu_aux), B, H, W, C, keep=(dcol, din, relu_aux))
 
+    def resize_to_cl(self, src, dst, tabs, B, C, Hi, Wi, Ho, Wo, ld, coff):
+        """tabs = (yi, yw, xi, xw) of head_engine.bilinear_tables, flattened, on the device."""
+        _chk(src, torch.float32, 'src'), _chk(dst, torch.bfloat16, 'dst')
+        self._add('vp_resize_to_cl_bf16', _p(src), _p(dst), *[_p(t) for t in tabs], B, C, Hi, Wi, Ho, Wo, ld, coff,
+                  keep=(src, dst, tabs))
+
+    def resize_to_cl_bwd(self, g, dx, ttabs, B, C, Hi, Wi, Ho, Wo, ld, coff):
+        """ttabs = (tyi, tyw, txi, txw): the transposed lists [Hi][Ly], [Wi][Lx]."""
+        _chk(g, torch.bfloat16, 'g'), _chk(dx, torch.float32, 'dx')
+        self._add('vp_resize_to_cl_bwd', _p(g), _p(dx), *[_p(t) for t in ttabs], ttabs[0].shape[1], ttabs[2].shape[1],
+                  B, C, Hi, Wi, Ho, Wo, ld, coff, keep=(g, dx, ttabs))
+
     def deconv_weight_pad4(self, w, w4, n, k):
         """w [n][k][k] (k 2 or 3) -> the equivalent 4 x 4 kernel w4 [n][4][4] (f32)."""
         _chk(w, torch.float32, 'w'), _chk(w4, torch.float32, 'w4')
