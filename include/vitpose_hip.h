@@ -86,7 +86,9 @@ typedef struct vp_gemm_args {
                                     (k-contiguous x, no K split: VP_ERR_UNSUPPORTED otherwise); 5: 192x192 tiles, one
                                     persistent workgroup per CU that writes output tile i while it accumulates tile i + 1
                                     (k-contiguous x, bf16 outputs VP_EPI_BF16 / GELU / DGELU, K >= 640, M % 192 == 0,
-                                    no K split / row remap / colscale: VP_ERR_UNSUPPORTED otherwise) */
+                                    no K split / row remap / colscale: VP_ERR_UNSUPPORTED otherwise); 6: 192x128 tiles of
+                                    the three-stage kernel of mode 3 (1 / CU; k-contiguous x, no K split: VP_ERR_UNSUPPORTED
+                                    otherwise): N = 1024 at 6144 rows is exactly 256 such tiles */
     /* optional per-image routing of the Y operand: the mixture-of-experts FFN of ViTPose+ (MoEMlp.forward,
      * mmpose/models/backbones/vit_moe.py:98-115: the last `part_features` output channels of fc2 come from the
      * expert Linear selected by the image's dataset index).  Rows are images of exactly 192 tokens (M % 192 == 0);

@@ -749,22 +749,25 @@ def test_wgrad_grouped_exact(dev, mode):
             assert torch.equal(rest[-1], x.float().sum(0))
 
 
-# ------------------------------------------------------------------ 192 x 128 tiles, 2 workgroups / CU
+# ------------------------------------------------------------------ 192 x 128 tiles: 2 workgroups / CU (tile_mode 4), and the
+# three-stage one-workgroup-per-CU kernel on the same tile (tile_mode 6)
+@pytest.mark.parametrize('mode', [4, 6])
 @pytest.mark.parametrize('yk', [False, True])
 @pytest.mark.parametrize('M,N,K', [(768, 512, 256), (520, 264, 320), (192, 128, 64), (1152, 768, 768), (200, 136, 192),
-                                   (8, 8, 64)])
-def test_gemm_w2_layouts_exact(dev, yk, M, N, K):
+                                   (8, 8, 64), (1536, 1024, 1024)])
+def test_gemm_w2_layouts_exact(dev, mode, yk, M, N, K):
     from vitpose_amd import _lib
     X, Y = ints((M, K), dev, seed=1), ints((N, K), dev, seed=2)
     ys = (Y.t() if yk else Y).contiguous().bfloat16()
     for rep in range(2):
         out = torch.full((M, N), float('nan'), device=dev)
         run(lambda p: p.gemm(X.bfloat16(), ys, out, M, N, K, ldx=K, ldy=ys.shape[1], ldo=N, y_kmajor=yk,
-                             epilogue=_lib.VP_EPI_F32, tile_mode=4))
+                             epilogue=_lib.VP_EPI_F32, tile_mode=mode))
         assert torch.equal(out, X @ Y.t()), rep
 
 
-def test_gemm_w2_epilogues(dev):
+@pytest.mark.parametrize('mode', [4, 6])
+def test_gemm_w2_epilogues(dev, mode):
     from vitpose_amd import _lib
     M, N, K, T = 768, 512, 256, 192
     X, Y = rnd((M, K), dev, 3).bfloat16(), rnd((N, K), dev, 4, 0.1).bfloat16()
@@ -773,7 +776,7 @@ def test_gemm_w2_epilogues(dev):
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     u = torch.empty_like(out)
     run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, out2=u, epilogue=_lib.VP_EPI_GELU,
-                         tile_mode=4))
+                         tile_mode=mode))
     torch.testing.assert_close(u.float(), (acc + bias).bfloat16().float(), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(acc + bias), rtol=2e-2, atol=2e-2)
     g = rnd((M, N), dev, 6).bfloat16()              # DGELU: dgrad product (y k-major) masked by gelu'(aux)
@@ -781,7 +784,7 @@ def test_gemm_w2_epilogues(dev):
     du = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
     aux = rnd((M, K), dev, 9).bfloat16()
     run(lambda p: p.gemm(g, Wt, du, M, K, N, ldx=N, ldy=K, ldo=K, y_kmajor=True, epilogue=_lib.VP_EPI_DGELU, aux=aux,
-                         ldaux=K, tile_mode=4))
+                         ldaux=K, tile_mode=mode))
     a32 = aux.float().requires_grad_()
     torch.nn.functional.gelu(a32).sum().backward()
     torch.testing.assert_close(du.float(), (g.float() @ Wt.float()) * a32.grad, rtol=2e-2, atol=2e-2)
@@ -789,12 +792,12 @@ def test_gemm_w2_epilogues(dev):
     rs = torch.tensor([0.0, 1.0 / 0.7, 1.0, 2.0], device=dev)
     o32 = torch.empty(M, N, device=dev)
     run(lambda p: p.gemm(X, Y, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, resid=resid, rowscale=rs,
-                         rows_per_scale=T, epilogue=_lib.VP_EPI_RESID_F32, tile_mode=4))
+                         rows_per_scale=T, epilogue=_lib.VP_EPI_RESID_F32, tile_mode=mode))
     torch.testing.assert_close(o32, resid + rs.repeat_interleave(T)[:, None] * (acc + bias), rtol=1e-4, atol=1e-4)
     bad = torch.empty(K, M, device=dev, dtype=torch.bfloat16)
     with pytest.raises(Exception):                 # k-major x is outside this schedule
         run(lambda p: p.gemm(bad, Y, o32, M, N, K, ldx=M, ldy=K, ldo=N, x_kmajor=True, epilogue=_lib.VP_EPI_F32,
-                             tile_mode=4))
+                             tile_mode=mode))
 
 
 # ------------------------------------------------------------------ persistent 192 x 192 tiles (tile_mode 5)

@@ -18,9 +18,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tokens', type=int, default=12288)
     ap.add_argument('--embed', type=int, default=768)
-    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--reps', type=int, default=50)
     ap.add_argument('--only', default='')
-    ap.add_argument('--tile-mode', type=int, default=0, help='0 autotuned, 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = 192x192 tiles')
+    ap.add_argument('--tile-mode', type=int, default=0, help='0 autotuned, 1 = 128x128 tiles, 2 = 256x256, 3 = 192x192, 4 = 192x128 with two workgroups per CU, '
+                    '5 = persistent 192x192, 6 = 192x128 with one workgroup per CU')
     ap.add_argument('--group-blocks', type=int, default=4)
     ap.add_argument('--wsplit', type=int, default=0, help='override the wgrad K split')
     args = ap.parse_args()
@@ -85,7 +86,15 @@ def main():
         except Exception as exc:  # noqa: BLE001  (a schedule that does not cover this layout)
             print(f'{name:45s} unsupported ({exc})')
             continue
-        for _ in range(3):
+        # warm up for ~40 ms of back-to-back launches: the clock of an idle GPU needs that long to settle, and a
+        # candidate measured right after host-side set-up (idle GPU) otherwise reads 10-15 % slow
+        t_w = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_w[0].record()
+        for _ in range(20):
+            p.run()
+        t_w[1].record()
+        torch.cuda.synchronize()
+        for _ in range(int(40.0 / max(t_w[0].elapsed_time(t_w[1]) / 20, 1e-3))):
             p.run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1128,6 +1128,14 @@ __device__ __forceinline__ void stage_unit_routed(const Operand& op, int r0, int
                                      (__attribute__((address_space(3))) void*)(lds + base * 16), 16, 0, 0);
 }
 
+template <int N_>
+using ic = std::integral_constant<int, N_>;
+
+template <int N_>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
 // fragment `f` (16 rows / columns) of a 192-wide operand tile made of three 64-wide units
 template <bool KMAJ>
 __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s, int lane) {
@@ -1148,12 +1156,16 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* op_units, int f, int s,
 // KMAP (grouped weight gradients only): a problem may reduce over a SUBSET of the images whose rows make up the
 // K extent: bit b of its image_mask words selects image b (tiles_per_image K tiles each; no bit set = the output
 // is written as zeros).  The K loop walks the set bits with scalar ALU work only (no memory access in the loop).
-template <bool XKMAJ, bool YKMAJ, int EPI, bool ROUTE = false, bool KMAP = false, bool SPLIT3 = false>
+// NU = 64-column units of the Y tile: 3 = the 192 x 192 tile, 2 = a 192 x 128 tile (a wave owns 96 x 32: 6 x 2 fragments)
+// for products whose 192-wide column tiles would not fill the chip (N = 1024 at 6144 rows: 256 tiles of 192 x 128).
+template <bool XKMAJ, bool YKMAJ, int EPI, bool ROUTE = false, bool KMAP = false, bool SPLIT3 = false, int NU = 3>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Operand Y, int M, int N, int K,
                                                                 int tiles_n, int ntiles, int ksplit_tiles, Epi e,
                                                                 const vp_group_entry* gtab, int ngtab,
                                                                 Route rt = Route{nullptr, nullptr, nullptr, 0}) {
-    __shared__ __attribute__((aligned(16))) char lds[3][STAGE3_BYTES];
+    static_assert(NU == 3 || (NU == 2 && !ROUTE && !KMAP), "routed / masked launches use the 192-wide tile");
+    constexpr int STAGE_BYTES = (3 + NU) * UNIT_BYTES, WCOLS = 16 * NU, TN = 64 * NU;
+    __shared__ __attribute__((aligned(16))) char lds[3][STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
@@ -1173,7 +1185,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     const int tiles_m = ntiles / tiles_n;
     const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
     const int gm = min(tiles_m - gid * 8, 8);
-    const int i0 = (gid * 8 + tin % gm) * T3, j0 = (tin / gm) * T3;
+    const int i0 = (gid * 8 + tin % gm) * T3, j0 = (tin / gm) * TN;
     const int nk_all = K / BK;
     const int kt0 = slice * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
@@ -1215,17 +1227,17 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     if constexpr (ROUTE) {
         const int ex = rt.expert[i0 / T3];
         ydelta = rt.delta[ex];
-        if (e.bias && rt.bias_delta && j0 + wc * 48 >= rt.split) e.bias += rt.bias_delta[ex];
+        if (e.bias && rt.bias_delta && j0 + wc * WCOLS >= rt.split) e.bias += rt.bias_delta[ex];
     }
 
-    f32x4 acc[6][3];
+    f32x4 acc[6][NU];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NU; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     // residual / position addend of this wave's block: in flight under the whole K loop
-    f32x4 pre[EPI == VP_EPI_RESID_F32 ? 6 : 1][3];
-    if constexpr (EPI == VP_EPI_RESID_F32) load_addend<6, 3>(e, pre, i0 + grp * 96, j0 + wc * 48, lane, M, N);
+    f32x4 pre[EPI == VP_EPI_RESID_F32 ? 6 : 1][NU];
+    if constexpr (EPI == VP_EPI_RESID_F32) load_addend<6, NU>(e, pre, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N);
     constexpr bool ROWSUM = XKMAJ && YKMAJ && EPI == VP_EPI_F32;
     const bool do_rs = ROWSUM && rowsum != nullptr && j0 == 0;   // workgroup-uniform; fragment a goes to wave a % 4
     f32x4 racc[ROWSUM ? 6 : 1];
@@ -1254,11 +1266,11 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         };
         pick(0);
 #pragma unroll
-        for (int un = 0; un < 6; ++un) stage(un, 0, 0);
+        for (int un = 0; un < 3 + NU; ++un) stage(un, 0, 0);
         pick(1);
 #pragma unroll
-        for (int un = 0; un < 6; ++un) stage(un, 1, 1);
-        VP_WAIT_VM(6);
+        for (int un = 0; un < 3 + NU; ++un) stage(un, 1, 1);
+        wait_vm<3 + NU>();
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
 
@@ -1268,12 +1280,12 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             pick(u + 2);
             const char* lx = lds[cur];
             const char* ly = lds[cur] + 3 * UNIT_BYTES;
-            bf16x8 xf[3][2], yf[3][2];
+            bf16x8 xf[3][2], yf[NU][2];
             // ---- phase 0: rows 0-47 of the wave's block
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                for (int b = 0; b < 3; ++b) yf[b][s] = read_frag3<YKMAJ>(ly, 3 * wc + b, s, lane);
+                for (int b = 0; b < NU; ++b) yf[b][s] = read_frag3<YKMAJ>(ly, NU * wc + b, s, lane);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) xf[a][s] = read_frag3<XKMAJ>(lx, 6 * grp + a, s, lane);
             }
@@ -1289,7 +1301,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b)
+                    for (int b = 0; b < NU; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
                                                                           acc[a][b], 0, 0, 0);
             if constexpr (RS) {
@@ -1311,8 +1323,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
                 for (int a = 0; a < 3; ++a) xf[a][s] = read_frag3<XKMAJ>(lx, 6 * grp + 3 + a, s, lane);
             stage(2, u + 2, nxt2);
             stage(4, u + 2, nxt2);
-            stage(5, u + 2, nxt2);
-            VP_WAIT_VM(6);
+            if constexpr (NU == 3) stage(5, u + 2, nxt2);
+            wait_vm<3 + NU>();
             __builtin_amdgcn_s_barrier();
             if constexpr (XKMAJ) lds_fence(xf);
             __builtin_amdgcn_s_setprio(1);
@@ -1321,7 +1333,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b)
+                    for (int b = 0; b < NU; ++b)
                         acc[3 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
                                                                           acc[3 + a][b], 0, 0, 0);
             if constexpr (RS) {
@@ -1354,8 +1366,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     if constexpr (epi_is_bf16<EPI>()) {
         if (((N | e.ldo) & 7) == 0) {
             __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free for staging
-            run_epilogue_staged<EPI, 6, 3, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N,
-                                              &lds[0][0] + wave * (48 * 112));
+            run_epilogue_staged<EPI, 6, NU, 3>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N,
+                                               &lds[0][0] + wave * (48 * (NU * 32 + 16)));
             return;
         }
     }
@@ -1363,9 +1375,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         if (do_rs) store_rowsum<6>(rowsum, racc, i0 + grp * 96, lane, M, wc);
     }
     if constexpr (EPI == VP_EPI_RESID_F32)
-        run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice, pre);
+        run_epilogue<EPI, 6, NU>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, slice, pre);
     else
-        run_epilogue<EPI, 6, 3>(e, acc, i0 + grp * 96, j0 + wc * 48, lane, M, N, slice);
+        run_epilogue<EPI, 6, NU>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, slice);
 }
 
 
@@ -1387,13 +1399,6 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
 // counted wait of the K loop between them and their use.
 // Needs K >= 10 * 64 (one fragment per phase, 18 fragments, after one K tile without).  bf16 outputs (VP_EPI_BF16 / GELU / DGELU), no row remap,
 // no column scale.
-template <int N_>
-using ic = std::integral_constant<int, N_>;
-
-template <int N_>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
-}
 // Global loads the compiler does not track (it would otherwise wait for EVERY outstanding vector-memory operation,
 // the LDS-DMA prefetches included, in front of their first use inside the K loop): the caller guarantees that a
 // counted wait lies between the load and loaded(), which ties the register to that point of the program.
@@ -1766,6 +1771,32 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
                     return VP_ERR_UNSUPPORTED;
             }
 #undef VP_GEMM5_CASE
+        }
+        VP_LAUNCH_RET();
+    }
+    if (a->tile_mode == 6) {
+        // 192 x 128 tiles of the 192-tile kernel (one workgroup per CU): forward / data-gradient products whose
+        // 192-wide column tiles would leave CUs idle
+        if (XK || split > 1) return VP_ERR_UNSUPPORTED;
+        const int tm6 = (a->M + T3 - 1) / T3, tn6 = (a->N + 127) / 128, nt6 = tm6 * tn6;
+        if constexpr (!XK) {
+#define VP_GEMM6_CASE(EPI)                                                                                        \
+    case EPI:                                                                                                     \
+        hipLaunchKernelGGL((gemm192_kernel<false, YK, EPI, false, false, false, 2>), dim3(nt6), dim3(T2_THREADS), 0, \
+                           st, X, Y, a->M, a->N, a->K, tn6, nt6, ksplit_tiles, e, nullptr, 0);                    \
+        break;
+            switch (a->epilogue) {
+                VP_GEMM6_CASE(VP_EPI_BF16)
+                VP_GEMM6_CASE(VP_EPI_GELU)
+                VP_GEMM6_CASE(VP_EPI_RESID_F32)
+                VP_GEMM6_CASE(VP_EPI_DGELU)
+                VP_GEMM6_CASE(VP_EPI_F32)
+                VP_GEMM6_CASE(VP_EPI_SCALE_RELU)
+                VP_GEMM6_CASE(VP_EPI_DRELU)
+                default:
+                    return VP_ERR_ARG;
+            }
+#undef VP_GEMM6_CASE
         }
         VP_LAUNCH_RET();
     }

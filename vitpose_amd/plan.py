@@ -263,7 +263,7 @@ class Plan:
                         a.tile_mode = mode
                         return fn(ctypes.byref(a), s_)
                     return f
-                modes = [1, 2, 3] if x_kmajor else [1, 2, 3, 4]
+                modes = [1, 2, 3] if x_kmajor else ([1, 2, 3, 4] if split3 else [1, 2, 3, 4, 6])
                 if (not x_kmajor and not split3 and K >= 640 and M % 192 == 0 and row_map is None and colscale is None
                         and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_GELU, _lib.VP_EPI_DGELU)
                         and (M // 192) * ((N + 191) // 192) > 256):
