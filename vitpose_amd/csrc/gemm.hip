@@ -788,16 +788,27 @@ __device__ __forceinline__ bf16x8 ones8() {
     for (int i = 0; i < 8; ++i) o[i] = (bf16)1.0f;
     return o;
 }
-template <int FM>
-__device__ __forceinline__ void store_rowsum(float* rowsum, const f32x4 (&racc)[FM], int row0, int lane, int M,
-                                             int wc) {
-    if (lane < 16) {
+// Fragment `idx` (wave-uniform) of a register array of fragments, by selects: a branch per candidate would cut the
+// MFMA stream of the loop into small basic blocks.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NF>
+__device__ __forceinline__ bf16x8 pick_frag(const bf16x8 (&f)[NF][2], int idx, int s) {
+    // (selected as four dwords: a select on the bf16 vector type is done element by element)
+    u32x4 r = __builtin_bit_cast(u32x4, f[0][s]);
 #pragma unroll
-        for (int a = 0; a < FM; ++a) {
-            const int row = row0 + a * 16 + lane;
-            if ((a & 3) == wc && row < M) rowsum[row] = racc[a][0];   // fragment a was summed by wave a % 4
-        }
+    for (int i = 1; i < NF; ++i) {
+        const u32x4 c = __builtin_bit_cast(u32x4, f[i][s]);
+        const bool hit = idx == i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = hit ? c[j] : r[j];
     }
+    return __builtin_bit_cast(bf16x8, r);
+}
+// One wave's row sums of fragment `a` (rows row0 + 16 a ...): every accumulator row holds the same sums
+__device__ __forceinline__ void store_rowsum(float* rowsum, const f32x4& racc, int row0, int a, bool valid, int lane,
+                                             int M) {
+    const int row = row0 + a * 16 + lane;
+    if (valid && lane < 16 && row < M) rowsum[row] = racc[0];
 }
 
 
@@ -891,9 +902,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr bool ROWSUM = XKMAJ && YKMAJ && EPI == VP_EPI_F32;
     const bool do_rs = ROWSUM && rowsum != nullptr && j0 == 0;   // workgroup-uniform; fragment a goes to wave a % 4
-    f32x4 racc[ROWSUM ? 8 : 1];
-#pragma unroll
-    for (int a = 0; a < (ROWSUM ? 8 : 1); ++a) racc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // row sums: wave wc sums fragment wc of the group's rows 0-63 (phase 0) and of its rows 64-127 (phase 2)
+    f32x4 rlo = f32x4{0.f, 0.f, 0.f, 0.f}, rhi = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16x8 ones = ones8();
 
     // the K loop exists twice (generic lambda): with and without the row-sum MFMAs, so that the tiles
@@ -957,14 +967,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
                                                                           acc[a][b], 0, 0, 0);
             if constexpr (RS) {
-                {
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int a = 0; a < 4; ++a)
-                            if (wc == a)
-                                racc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[a], 0, 0, 0);
-                }
+                for (int s = 0; s < 2; ++s)
+                    rlo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pick_frag<4>(xf, wc, s), rlo, 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
@@ -1005,15 +1010,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
                         acc[4 + a][2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
                                                                           acc[4 + a][2 + b], 0, 0, 0);
             if constexpr (RS) {
-                {
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int a = 0; a < 4; ++a)
-                            if (wc == a)
-                                racc[4 + a] =
-                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[4 + a], 0, 0, 0);
-                }
+                for (int s = 0; s < 2; ++s)
+                    rhi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pick_frag<4>(xf, wc, s), rhi, 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
@@ -1054,7 +1053,10 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
         }
     }
     if constexpr (ROWSUM) {
-        if (do_rs) store_rowsum<8>(rowsum, racc, i0 + grp * 128, lane, M, wc);
+        if (do_rs) {
+            store_rowsum(rowsum, rlo, i0 + grp * 128, wc, true, lane, M);
+            store_rowsum(rowsum, rhi, i0 + grp * 128, 4 + wc, true, lane, M);
+        }
     }
     run_epilogue<EPI, 8, 4>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N, slice);
 }
@@ -1240,10 +1242,14 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     if constexpr (EPI == VP_EPI_RESID_F32) load_addend<6, NU>(e, pre, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N);
     constexpr bool ROWSUM = XKMAJ && YKMAJ && EPI == VP_EPI_F32;
     const bool do_rs = ROWSUM && rowsum != nullptr && j0 == 0;   // workgroup-uniform; fragment a goes to wave a % 4
-    f32x4 racc[ROWSUM ? 6 : 1];
-#pragma unroll
-    for (int a = 0; a < (ROWSUM ? 6 : 1); ++a) racc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = ones8();
+    // row sums: fragment a of the group's six goes to wave a % 4 -- phase 0 (fragments 0-2): wave wc sums fragment wc
+    // (wave 3 none); phase 1 (fragments 3-5): wave wc sums fragment 3 + (wc + 1) % 4 (wave 2 none).  A wave without a
+    // fragment multiplies by zeros instead of ones: no branch in the MFMA stream.
+    f32x4 r0 = f32x4{0.f, 0.f, 0.f, 0.f}, r1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rs_a1 = (wc + 1) & 3;
+    bf16x8 ones0 = ones8(), ones1 = ones8();
+    if (wc == 3) ones0 = bf16x8{};
+    if (rs_a1 == 3) ones1 = bf16x8{};
 
     // the K loop exists twice (generic lambda): with and without the row-sum MFMAs, so that the tiles
     // without row sums (most of them) run the loop that has no trace of them
@@ -1305,14 +1311,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
                                                                           acc[a][b], 0, 0, 0);
             if constexpr (RS) {
-                {
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int a = 0; a < 3; ++a)
-                            if (wc == a)
-                                racc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[a], 0, 0, 0);
-                }
+                for (int s = 0; s < 2; ++s)
+                    r0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones0, pick_frag<3>(xf, wc, s), r0, 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
@@ -1337,15 +1338,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
                         acc[3 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b][SPLIT3 ? t == 2 : t], xf[a][SPLIT3 ? t == 1 : t],
                                                                           acc[3 + a][b], 0, 0, 0);
             if constexpr (RS) {
-                {
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int a = 0; a < 3; ++a)
-                            if (wc == ((3 + a) & 3))
-                                racc[3 + a] =
-                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[a][s], racc[3 + a], 0, 0, 0);
-                }
+                for (int s = 0; s < 2; ++s)
+                    r1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones1, pick_frag<3>(xf, rs_a1, s), r1, 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
@@ -1372,7 +1367,10 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         }
     }
     if constexpr (ROWSUM) {
-        if (do_rs) store_rowsum<6>(rowsum, racc, i0 + grp * 96, lane, M, wc);
+        if (do_rs) {
+            store_rowsum(rowsum, r0, i0 + grp * 96, wc, wc < 3, lane, M);
+            store_rowsum(rowsum, r1, i0 + grp * 96, 3 + rs_a1, rs_a1 < 3, lane, M);
+        }
     }
     if constexpr (EPI == VP_EPI_RESID_F32)
         run_epilogue<EPI, 6, NU>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, slice, pre);

@@ -40,6 +40,8 @@ _TUNE_CACHE = {}
 AUTOTUNE = os.environ.get('VITPOSE_AUTOTUNE', '1') != '0'
 # VITPOSE_TUNE_OVERRIDE="<xk><yk>:<epilogue>:<N>:<K>=<tile_mode>,...": pins the tile schedule of a product class (whole-step
 # A/B runs of one schedule against the record-time pick), e.g. "00:2:768:3072=2" = fc2 + residual on the 256 tiles
+# VITPOSE_WGRAD_GROUP_TILE=2|3 pins the tile size of the grouped weight-gradient launch (256 / 192) the same way
+_GROUP_TILE_OVERRIDE = int(os.environ.get('VITPOSE_WGRAD_GROUP_TILE', '0'))
 _TUNE_OVERRIDE = {k: int(v) for k, v in (kv.split('=') for kv in os.environ.get('VITPOSE_TUNE_OVERRIDE', '').split(',') if kv)}
 
 
@@ -351,6 +353,8 @@ class Plan:
                 raise KernelError(f'vp_wgrad_group_table -> {rc}')
             blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             return blob, total.value
+        if tile_mode == 0 and _GROUP_TILE_OVERRIDE in (2, 3):
+            tile_mode = _GROUP_TILE_OVERRIDE
         if tile_mode == 0:
             key = ('wgrad_group', tuple((p[3], p[4]) for p in problems), K, str(dev))
             if AUTOTUNE and key not in _TUNE_CACHE:
