@@ -1264,6 +1264,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             }
         };
         auto stage = [&](int unit, int u, int st) {
+#ifdef VP_ABLATE_NOLOAD
+            if (u >= 2) return;     // ablation build: only the pipeline fill is loaded (timing of a loop without operand traffic)
+#endif
             const int k0 = kstage;
             char* dst = lds[st] + unit * UNIT_BYTES;
             if (unit < 3) stage_unit<XKMAJ>(X, i0 + unit * 64, k0, dst, wave, lane);
