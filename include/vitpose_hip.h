@@ -88,7 +88,10 @@ typedef struct vp_gemm_args {
                                     (k-contiguous x, bf16 outputs VP_EPI_BF16 / GELU / DGELU, K >= 640, M % 192 == 0,
                                     no K split / row remap / colscale: VP_ERR_UNSUPPORTED otherwise); 6: 192x128 tiles of
                                     the three-stage kernel of mode 3 (1 / CU; k-contiguous x, no K split: VP_ERR_UNSUPPORTED
-                                    otherwise): N = 1024 at 6144 rows is exactly 256 such tiles */
+                                    otherwise): N = 1024 at 6144 rows is exactly 256 such tiles; 7: 192x192 tiles, the two
+                                    wave groups split every K tile (96x96 per wave; the halves are summed through LDS once per
+                                    tile): long reductions; epilogues VP_EPI_BF16 / RESID_F32 / F32, K >= 128, no K split:
+                                    VP_ERR_UNSUPPORTED otherwise */
     /* optional per-image routing of the Y operand: the mixture-of-experts FFN of ViTPose+ (MoEMlp.forward,
      * mmpose/models/backbones/vit_moe.py:98-115: the last `part_features` output channels of fc2 come from the
      * expert Linear selected by the image's dataset index).  Rows are images of exactly 192 tokens (M % 192 == 0);
@@ -302,7 +305,7 @@ int vp_deconv_weight_pad4(const float* w, float* w4, size_t n, int ksize, vp_str
  * tiles of all problems together fill the chip in whole rounds (the Linear weight gradients of several Blocks,
  * vit.py:93-95,60-62 under autograd; none of them alone has enough tiles).
  *   vp_wgrad_group_table: host-side; fills tiles_n / ntiles / tile0 of `problems` (host memory, <= 64 entries)
- *     for the tile size (tile_mode 2: 256, 3: 192) and returns the grid size in *total_tiles.  The caller copies
+ *     for the tile size (tile_mode 2: 256, 3 and 7: 192) and returns the grid size in *total_tiles.  The caller copies
  *     the filled array to device memory.
  *   vp_wgrad_grouped_bf16: the launch; `table_dev` is that device copy. */
 typedef struct vp_group_entry {

@@ -603,6 +603,51 @@ def test_gemm256_epilogues_and_splitk(dev, mode):
     assert torch.equal(dw, A.float().t() @ Bm.float())
 
 
+# ------------------------------------------------------------------ 192 x 192 tiles, K tile split between the wave groups
+@pytest.mark.parametrize('xk,yk', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(512, 256, 256), (520, 264, 320), (192, 192, 128), (1024, 768, 768), (384, 192, 192),
+                                   (576, 392, 448), (8, 8, 128)])
+def test_gemm_ksplit_layouts_exact(dev, xk, yk, M, N, K):
+    """tile_mode 7 (a wave owns a 96 x 96 block for one 32-wide half of every K tile; the halves meet through LDS):
+    integer operands, so any fragment / sub-step / exchange mistake shows as a mismatch.  Partial tiles, 2 .. 12 K tiles."""
+    from vitpose_amd import _lib
+    X = ints((M, K), dev, seed=1)
+    Y = ints((N, K), dev, seed=2)
+    ref = X @ Y.t()
+    xs = (X.t() if xk else X).contiguous().bfloat16()
+    ys = (Y.t() if yk else Y).contiguous().bfloat16()
+    for rep in range(3):
+        out = torch.full((M, N), float('nan'), device=dev)
+        run(lambda p: p.gemm(xs, ys, out, M, N, K, ldx=xs.shape[1], ldy=ys.shape[1], ldo=N, x_kmajor=xk, y_kmajor=yk,
+                             epilogue=_lib.VP_EPI_F32, tile_mode=7))
+        assert torch.equal(out, ref), rep
+
+
+def test_gemm_ksplit_epilogues(dev):
+    from vitpose_amd import _lib
+    M, N, K, T = 768, 512, 256, 192
+    X, Y = rnd((M, K), dev, 3).bfloat16(), rnd((N, K), dev, 4, 0.1).bfloat16()
+    bias = rnd((N,), dev, 5)
+    acc = X.float() @ Y.float().t()
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, epilogue=_lib.VP_EPI_BF16, tile_mode=7))
+    torch.testing.assert_close(out.float(), (acc + bias).bfloat16().float(), rtol=1e-2, atol=1e-2)
+    Wt = rnd((N, K), dev, 8, 0.1).bfloat16()        # dgrad layout: [reduction = N][outputs = K]
+    g = rnd((M, N), dev, 6).bfloat16()
+    dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.gemm(g, Wt, dx, M, K, N, ldx=N, ldy=K, ldo=K, y_kmajor=True, epilogue=_lib.VP_EPI_BF16, tile_mode=7))
+    torch.testing.assert_close(dx.float(), g.float() @ Wt.float(), rtol=2e-2, atol=2e-2)
+    resid = rnd((M, N), dev, 7)
+    rs = torch.tensor([0.0, 1.0 / 0.7, 1.0, 2.0], device=dev)
+    o32 = torch.empty(M, N, device=dev)
+    run(lambda p: p.gemm(X, Y, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, resid=resid, rowscale=rs,
+                         rows_per_scale=T, epilogue=_lib.VP_EPI_RESID_F32, tile_mode=7))
+    torch.testing.assert_close(o32, resid + rs.repeat_interleave(T)[:, None] * (acc + bias), rtol=1e-4, atol=1e-4)
+    with pytest.raises(Exception):                 # a single K tile has no second half to split off
+        run(lambda p: p.gemm(X[:, :64].contiguous(), Y[:, :64].contiguous(), o32, M, N, 64, ldx=64, ldy=64, ldo=N,
+                             epilogue=_lib.VP_EPI_F32, tile_mode=7))
+
+
 # ------------------------------------------------------------------ fp32-accurate path
 def to_pair(x):
     """Reference of the hi / lo pair layout: [R][K] f32 -> [R][2K] bf16, groups of 32 hi then their 32 lo."""
@@ -729,7 +774,7 @@ def test_deconv_fwd_split(dev):
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('mode', [2, 3])
+@pytest.mark.parametrize('mode', [2, 3, 7])
 def test_wgrad_grouped_exact(dev, mode):
     """Several weight-gradient problems of different shapes in one launch: every tile finds its own
     problem (integer data: exact), including edge tiles and outputs with a wider leading dimension."""

@@ -20,7 +20,7 @@ def main():
     ap.add_argument('--embed', type=int, default=768)
     ap.add_argument('--reps', type=int, default=50)
     ap.add_argument('--only', default='')
-    ap.add_argument('--tile-mode', type=int, default=0, help='0 autotuned, 1 = 128x128 tiles, 2 = 256x256, 3 = 192x192, 4 = 192x128 with two workgroups per CU, '
+    ap.add_argument('--tile-mode', type=int, default=0, help='0 autotuned, 1 = 128x128 tiles, 2 = 256x256, 3 = 192x192, 4 = 192x128 with two workgroups per CU, 7 = 192x192 K-split, '
                     '5 = persistent 192x192, 6 = 192x128 with one workgroup per CU')
     ap.add_argument('--group-blocks', type=int, default=4)
     ap.add_argument('--wsplit', type=int, default=0, help='override the wgrad K split')
@@ -75,7 +75,7 @@ def main():
             probs.append((rb(M, N), rb(M, K), torch.empty(N, K, device=dev), N, K, N, K))
     gflops = sum(2.0 * M * p[3] * p[4] for p in probs)
     cases.append((f'wgrad_group {args.group_blocks} blocks ({len(probs)} problems)', gflops,
-                  lambda p: p.wgrad_group(probs, M, tile_mode=args.tile_mode if args.tile_mode in (2, 3) else 0)))
+                  lambda p: p.wgrad_group(probs, M, tile_mode=args.tile_mode if args.tile_mode in (2, 3, 7) else 0)))
     for name, flops, build in cases:
         if args.only and args.only not in name:
             continue

@@ -1383,6 +1383,184 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
 
 
 // =====================================================================================
+// 192 x 192 x 64 tile with the K tile split between the two wave groups (tile_mode 7)
+// =====================================================================================
+// Wave (h, r, c) owns the 96 x 96 block (r, c) of the tile for the 32-wide sub-step h of every K tile: 6 + 6 fragment
+// reads feed 36 MFMAs (the 96 x 48 waves of gemm192_kernel read 12 + 6 for 36), one interval is 36 MFMAs long instead
+// of 18 and a K tile costs two barriers instead of four.  Measured on the bare structure (tools/probes/mfma_lds_probe):
+// 2050 TFLOP/s against 1580 for the 96 x 48 layout, i.e. the rate of an MFMA loop without any LDS traffic.  The price is
+// paid once per output tile: the partial sums of the two sub-steps meet through LDS (each wave hands 48 of its 96 rows
+// to its partner and finishes the other 48: 144 KiB, the three stages), so the layout is for long reductions -- the
+// grouped weight gradients and the K >= 2304 data-gradient / forward products.
+// Group h = 1 runs one barrier interval behind group h = 0 (its reads and LDS-DMA issue under the other group's MFMAs).
+// Per K tile u and wave: R(u) = [12 fragment reads of K tile u, LDS-DMA of K tile u + 2], barrier, C(u) = [36 MFMAs], barrier.
+// K tile u + 1 has to be complete before the barrier after which group 0 reads it: group 0 waits for its own loads at the
+// end of C(u), group 1 -- which reaches that same barrier at the end of its R(u) -- there.  The fragment reads are waited
+// for BEFORE the barrier that ends R: the stage they come from is overwritten by loads issued in the next interval.
+template <bool XKMAJ, bool YKMAJ, int EPI>
+__global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Operand Y, int M, int N, int K, int tiles_n,
+                                                                 int ntiles, Epi e, const vp_group_entry* gtab, int ngtab) {
+    __shared__ __attribute__((aligned(16))) char lds[3][STAGE3_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = wave >> 2, q = wave & 3, r = q >> 1, c = q & 1;
+    int work = xcd_remap(blockIdx.x, gridDim.x);
+    float* rowsum = nullptr;
+    if constexpr (XKMAJ && YKMAJ && EPI == VP_EPI_F32) {
+        if (gtab) rowsum = select_problem(gtab, ngtab, lane, work, X, Y, M, N, tiles_n, ntiles, e);
+    }
+    const int t = work;
+    const int tiles_m = ntiles / tiles_n;
+    const int gsz = 8 * tiles_n, gid = t / gsz, tin = t - gid * gsz;
+    const int gm = min(tiles_m - gid * 8, 8);
+    const int i0 = (gid * 8 + tin % gm) * T3, j0 = (tin / gm) * T3;
+    const int nk = K / BK;
+
+    f32x4 acc[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool ROWSUM = XKMAJ && YKMAJ && EPI == VP_EPI_F32;
+    const bool do_rs = ROWSUM && rowsum != nullptr && j0 == 0;
+    // row sums (bias gradients): one f32 per lane and X fragment, += the lane's 8 reduction elements of its row by four
+    // v_dot2c_f32_bf16 against (1, 1) per K tile -- VALU work in the shadow of the MFMAs, six registers (an MFMA against
+    // a ones operand, as in the kernels above, costs twelve accumulator registers more than this kernel has)
+    float rsv[ROWSUM ? 6 : 1];
+#pragma unroll
+    for (int a = 0; a < (ROWSUM ? 6 : 1); ++a) rsv[a] = 0.f;
+
+    auto k_loop = [&](auto rs_tag) {
+        constexpr bool RS = decltype(rs_tag)::value;
+        auto stage_all = [&](int u, int st) {
+            const int k0 = (u < nk ? u : nk - 1) * BK;
+#pragma unroll
+            for (int un = 0; un < 6; ++un) {
+                char* dst = lds[st] + un * UNIT_BYTES;
+                if (un < 3) stage_unit<XKMAJ>(X, i0 + un * 64, k0, dst, wave, lane);
+                else stage_unit<YKMAJ>(Y, j0 + (un - 3) * 64, k0, dst, wave, lane);
+            }
+        };
+        stage_all(0, 0);
+        stage_all(1, 1);
+        wait_vm<6>();
+        __builtin_amdgcn_s_barrier();
+        if (h == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one interval behind
+        int cur = 0, nxt2 = 2;
+#pragma unroll 1
+        for (int u = 0; u < nk; ++u) {
+            const char* lx = lds[cur];
+            const char* ly = lds[cur] + 3 * UNIT_BYTES;
+            bf16x8 xf[6], yf[6];
+            // (a k-major image keeps sub-step s of a unit 4096 bytes further on: the transposed read takes its offset as
+            // an immediate, so the wave's sub-step goes into the base address)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) yf[b] = read_frag3<YKMAJ>(ly + (YKMAJ ? h * 4096 : 0), 6 * c + b, YKMAJ ? 0 : h, lane);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) xf[a] = read_frag3<XKMAJ>(lx + (XKMAJ ? h * 4096 : 0), 6 * r + a, XKMAJ ? 0 : h, lane);
+            stage_all(u + 2, nxt2);
+            lds_fence(yf);
+            lds_fence(xf);
+            if (h == 1) wait_vm<6>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[b], xf[a], acc[a][b], 0, 0, 0);
+            if constexpr (RS) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, xf[a]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        asm("v_dot2c_f32_bf16 %0, %2, %1" : "+v"(rsv[a]) : "v"(w[i]), "s"(0x3f803f80u));
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (h == 0) wait_vm<6>();
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+        }
+        if (h == 0) __builtin_amdgcn_s_barrier();   // match group 1's extra barrier
+        VP_WAIT_VM(0);                               // no LDS-DMA may outlive the K loop: the stages are reused below
+    };
+    if (nk > 0) {
+        if constexpr (ROWSUM) {
+            if (do_rs) k_loop(std::true_type{});
+            else k_loop(std::false_type{});
+        } else {
+            k_loop(std::false_type{});
+        }
+    }
+    // ---- the two sub-step halves meet: wave (0, q) keeps rows 0-47 of its block, wave (1, q) rows 48-95; each hands the
+    // other half (18 fragments, 1 KiB each, lane-linear) to its partner through LDS
+    __builtin_amdgcn_s_barrier();                    // every wave's loads have landed and every read of the stages is done
+    char* flat = &lds[0][0];
+    f32x4* mine = reinterpret_cast<f32x4*>(flat + wave * 18432) + lane;
+    const f32x4* theirs = reinterpret_cast<const f32x4*>(flat + (wave ^ 4) * 18432) + lane;
+    if (h == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) mine[(a * 6 + b) * 64] = acc[3 + a][b];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) mine[(a * 6 + b) * 64] = acc[a][b];
+    }
+    __builtin_amdgcn_s_barrier();
+    if (h == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc[a][b] += theirs[(a * 6 + b) * 64];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc[a][b] = acc[3 + a][b] + theirs[(a * 6 + b) * 64];
+    }
+    f32x4 (&fin)[3][6] = reinterpret_cast<f32x4 (&)[3][6]>(acc);
+    const int row0 = i0 + r * 96 + h * 48, col0 = j0 + c * 96;
+    if constexpr (ROWSUM) {
+        if (do_rs) {                                 // (workgroup-uniform)
+            __builtin_amdgcn_s_barrier();            // the exchange has been read
+            // lane (g, li) holds the sum over its k chunks of row li: add the four lane groups, then the two sub-steps
+            // (the waves with c = 1 hold the same sums as their c = 0 neighbours and stay out)
+            float* part = reinterpret_cast<float*>(flat);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float v = rsv[a];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (c == 0 && lane < 16) part[((h * 2 + r) * 6 + a) * 16 + lane] = v;
+            }
+            __builtin_amdgcn_s_barrier();
+            if (h == 0 && c == 0 && lane < 16) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int row = i0 + r * 96 + a * 16 + lane;
+                    if (row < M) rowsum[row] = part[(r * 6 + a) * 16 + lane] + part[((2 + r) * 6 + a) * 16 + lane];
+                }
+            }
+        }
+    }
+    if constexpr (epi_is_bf16<EPI>()) {
+        if (((N | e.ldo) & 7) == 0) {
+            __builtin_amdgcn_s_barrier();            // the exchange has been read: LDS is free for the output transpose
+            run_epilogue_staged<EPI, 3, 6, 3>(e, fin, row0, col0, lane, M, N, flat + wave * (48 * 208));
+            return;
+        }
+    }
+    run_epilogue<EPI, 3, 6>(e, fin, row0, col0, lane, M, N);
+}
+
+
+// =====================================================================================
 // Persistent 192 x 192 x 64 kernel: the epilogue of tile i runs under the K loop of tile i + 1
 // =====================================================================================
 // One workgroup per CU walks a list of output tiles (tile = slot, slot + grid, ...) through ONE continuous K-tile
@@ -1801,6 +1979,25 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
         }
         VP_LAUNCH_RET();
     }
+    if (a->tile_mode == 7) {
+        // 192 x 192 tiles with the K tile split between the wave groups: long reductions, no K slices
+        if (split > 1 || nk < 2) return VP_ERR_UNSUPPORTED;
+        const int tm7 = (a->M + T3 - 1) / T3, tn7 = (a->N + T3 - 1) / T3, nt7 = tm7 * tn7;
+#define VP_GEMM7_CASE(EPI)                                                                                   \
+    case EPI:                                                                                                \
+        hipLaunchKernelGGL((gemm192k_kernel<XK, YK, EPI>), dim3(nt7), dim3(T2_THREADS), 0, st, X, Y, a->M,  \
+                           a->N, a->K, tn7, nt7, e, nullptr, 0);                                             \
+        break;
+        switch (a->epilogue) {
+            VP_GEMM7_CASE(VP_EPI_BF16)
+            VP_GEMM7_CASE(VP_EPI_RESID_F32)
+            VP_GEMM7_CASE(VP_EPI_F32)
+            default:
+                return VP_ERR_UNSUPPORTED;
+        }
+#undef VP_GEMM7_CASE
+        VP_LAUNCH_RET();
+    }
     if (a->tile_mode == 3) {
         const int tm3 = (a->M + T3 - 1) / T3, tn3 = (a->N + T3 - 1) / T3, nt3 = tm3 * tn3;
         dim3 grid3(nt3 * split);
@@ -1980,7 +2177,7 @@ extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
 static int group_tile(int tile_mode) { return tile_mode == 2 ? T2 : T3; }
 
 extern "C" int vp_wgrad_group_table(vp_group_entry* problems, int count, int tile_mode, int* total_tiles) {
-    VP_CHECK_ARG(problems && total_tiles && count > 0 && count <= 64 && (tile_mode == 2 || tile_mode == 3));
+    VP_CHECK_ARG(problems && total_tiles && count > 0 && count <= 64 && (tile_mode == 2 || tile_mode == 3 || tile_mode == 7));
     const int T = group_tile(tile_mode);
     int t0 = 0;
     for (int i = 0; i < count; ++i) {
@@ -2001,11 +2198,14 @@ extern "C" int vp_wgrad_group_table(vp_group_entry* problems, int count, int til
 extern "C" int vp_wgrad_grouped_bf16(const vp_group_entry* table_dev, int count, int total_tiles, int K,
                                      int tile_mode, hipStream_t stream) {
     VP_CHECK_ARG(table_dev && count > 0 && count <= 64 && total_tiles > 0 && K > 0 && K % BK == 0);
-    VP_CHECK_ARG(tile_mode == 2 || tile_mode == 3);
+    VP_CHECK_ARG(tile_mode == 2 || tile_mode == 3 || tile_mode == 7);
     Operand none{nullptr, 0, 0};
     Epi e{};
     e.kind = VP_EPI_F32;
-    if (tile_mode == 2)
+    if (tile_mode == 7)
+        hipLaunchKernelGGL((gemm192k_kernel<true, true, VP_EPI_F32>), dim3(total_tiles), dim3(T2_THREADS), 0, stream,
+                           none, none, 0, 0, K, 1, 1, e, table_dev, count);
+    else if (tile_mode == 2)
         hipLaunchKernelGGL((gemm256_kernel<true, true, VP_EPI_F32>), dim3(total_tiles), dim3(T2_THREADS), 0, stream,
                            none, none, 0, 0, K, 1, 1, K / BK, e, table_dev, count);
     else

@@ -40,8 +40,10 @@ _TUNE_CACHE = {}
 AUTOTUNE = os.environ.get('VITPOSE_AUTOTUNE', '1') != '0'
 # VITPOSE_TUNE_OVERRIDE="<xk><yk>:<epilogue>:<N>:<K>=<tile_mode>,...": pins the tile schedule of a product class (whole-step
 # A/B runs of one schedule against the record-time pick), e.g. "00:2:768:3072=2" = fc2 + residual on the 256 tiles
-# VITPOSE_WGRAD_GROUP_TILE=2|3 pins the tile size of the grouped weight-gradient launch (256 / 192) the same way
+# VITPOSE_WGRAD_GROUP_TILE=2|3|7 pins the tile schedule of the grouped weight-gradient launch (256 / 192 / 192 with the
+# K tile split between the wave groups) the same way
 _GROUP_TILE_OVERRIDE = int(os.environ.get('VITPOSE_WGRAD_GROUP_TILE', '0'))
+KSPLIT = os.environ.get('VITPOSE_KSPLIT', '1') == '1'      # tile_mode 7 among the autotune candidates
 _TUNE_OVERRIDE = {k: int(v) for k, v in (kv.split('=') for kv in os.environ.get('VITPOSE_TUNE_OVERRIDE', '').split(',') if kv)}
 
 
@@ -266,6 +268,8 @@ class Plan:
                         return fn(ctypes.byref(a), s_)
                     return f
                 modes = [1, 2, 3] if x_kmajor else ([1, 2, 3, 4] if split3 else [1, 2, 3, 4, 6])
+                if KSPLIT and not split3 and K >= 1536 and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_F32):
+                    modes.append(7)       # K tile split between the wave groups: pays for long reductions only
                 if (not x_kmajor and not split3 and K >= 640 and M % 192 == 0 and row_map is None and colscale is None
                         and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_GELU, _lib.VP_EPI_DGELU)
                         and (M // 192) * ((N + 191) // 192) > 256):
@@ -353,16 +357,17 @@ class Plan:
                 raise KernelError(f'vp_wgrad_group_table -> {rc}')
             blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             return blob, total.value
-        if tile_mode == 0 and _GROUP_TILE_OVERRIDE in (2, 3):
+        if tile_mode == 0 and _GROUP_TILE_OVERRIDE in (2, 3, 7):
             tile_mode = _GROUP_TILE_OVERRIDE
         if tile_mode == 0:
             key = ('wgrad_group', tuple((p[3], p[4]) for p in problems), K, str(dev))
             if AUTOTUNE and key not in _TUNE_CACHE:
                 s_ = c_void_p(torch.cuda.current_stream().cuda_stream)
-                tabs = {mode: table(mode) for mode in (2, 3)}
+                gmodes = (2, 3, 7) if KSPLIT else (2, 3)
+                tabs = {mode: table(mode) for mode in gmodes}
                 _TUNE_CACHE[key] = _pick_fastest({
                     mode: (lambda mode=mode: self.L.vp_wgrad_grouped_bf16(_p(tabs[mode][0]), n, tabs[mode][1], K, mode, s_))
-                    for mode in (2, 3)})
+                    for mode in gmodes})
             tile_mode = _TUNE_CACHE.get(key, 3)
         blob, total = table(tile_mode)
         keep = [blob] + [t for p in problems for t in p[:3]] + [t for p in problems for t in p[7:9]]
