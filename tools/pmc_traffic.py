@@ -12,7 +12,7 @@ requests of wide coalesced reads (16 B per lane, plain loads and LDS-DMA alike) 
 reports one half of the bytes: fetch bytes = 2 x FETCH_SIZE x 1024.  WRITE_SIZE is exact for
 16-byte-per-lane stores: write bytes = WRITE_SIZE x 1024.  Other access widths are uncalibrated.
 The launcher vp_gemm_bf16 picks one of four tile-schedule kernels per shape (vp_wgrad_grouped_bf16 runs
-gemm192_kernel / gemm256_kernel<true, true, 5, ...>); rows are keyed both by
+gemm192_kernel / gemm192k_kernel / gemm256_kernel<true, true, 5, ...>); rows are keyed both by
 the device kernel name and by the launcher instantiation vp_gemm_bf16<x_kmajor, y_kmajor, epilogue>."""
 import csv
 import json
@@ -46,13 +46,13 @@ def main():
         short = re.sub(r'\(.*$', '', short).replace('void ', '')
         res[short] = dict(launches=n, fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
                           hbm_bytes_per_launch=round(fb + wb))
-        m = re.match(r'gemm(?:192|256)?_kernel<(true|false), (true|false), (\d+)(?:, (?:true|false))*>', short)
+        m = re.match(r'gemm(?:192k?|192p|256)?_kernel<(true|false), (true|false), (\d+)(?:, (?:true|false|\d+))*>', short)
         key = None
         if m:
             key = f'vp_gemm_bf16<{m.group(1)}, {m.group(2)}, {m.group(3)}>'
             if m.group(1) == 'true' and m.group(2) == 'true' and m.group(3) == '5' and 'gemm_kernel' not in short:
                 key = 'vp_wgrad_grouped_bf16'      # the grouped launcher is the only user of this instantiation
-        m2 = re.match(r'gemm_w2_kernel<(true|false), (\d+)(?:, (?:true|false))*>', short)
+        m2 = re.match(r'gemm_w2_kernel<(true|false), (\d+)(?:, (?:true|false|\d+))*>', short)
         if m2:
             key = f'vp_gemm_bf16<false, {m2.group(1)}, {m2.group(2)}>'
         if key:
@@ -62,7 +62,7 @@ def main():
             g[2] += wb * n
     # the grouped launcher's autotune probes both tile sizes once; the steady state runs one of them:
     # report the variant with the most launches
-    variants = [(res[k]['launches'], k) for k in res if re.match(r'gemm(192|256)_kernel<true, true, 5(?:, (?:true|false))*>', k)]
+    variants = [(res[k]['launches'], k) for k in res if re.match(r'gemm(192k?|256)_kernel<true, true, 5(?:, (?:true|false|\d+))*>', k)]
     if variants:
         n, k = max(variants)
         groups['vp_wgrad_grouped_bf16'] = [n, res[k]['fetch_bytes_per_launch'] * n, res[k]['write_bytes_per_launch'] * n]
