@@ -3,7 +3,7 @@
 
 gelu(x)  = (x + |x|) / 2 - h(|x|),          h(a) = a erfc(a / sqrt 2) / 2
 gelu'(x) = 1/2 + copysign(1/2 - d(|x|), x), d(a) = h'(a) = erfc(a / sqrt 2) / 2 - a phi(a)
-h and d are smooth and decay like a Gaussian; on [0, A] each is fitted by a degree-15 polynomial in
+h and d are smooth and decay like a Gaussian; on [0, A] each is fitted by a degree-DEG polynomial in
 s = 2 a / A - 1 (Chebyshev least squares on a dense grid, converted to the monomial basis, whose
 coefficients stay below 2 in magnitude on [-1, 1]), and a is clamped to A beyond.  The script prints the
 coefficients and the maximum absolute error of the float32 Horner evaluation against scipy's erfc."""
@@ -11,7 +11,7 @@ import numpy as np
 from numpy.polynomial import chebyshev as C
 from scipy.special import erfc
 
-A, DEG = 5.0, 15
+A, DEG = 4.5, 11
 
 
 def h(a):

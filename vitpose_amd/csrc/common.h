@@ -82,39 +82,42 @@ __device__ __forceinline__ void lds_fence(bf16x8 (&f)[N_][S_]) {
 
 // GELU and its derivative WITHOUT transcendental instructions (v_exp / v_rcp issue at a quarter of the VALU rate, and
 // an erf evaluation with one v_rcp and one v_exp (Abramowitz & Stegun 7.1.26) costs ~90 VALU cycles per value: for a K = 768 product that is more VALU time in the epilogue
-// than MFMA time in the K loop).  With a = min(|x|, 5) and s = 2 a / 5 - 1:
+// than MFMA time in the K loop).  With a = min(|x|, 4.5) and s = 2 a / 4.5 - 1:
 //   gelu(x)  = (x + |x|) / 2 - h(a),          h(a) = a erfc(a / sqrt 2) / 2
 //   gelu'(x) = 1/2 + copysign(1/2 - d(a), x), d(a) = h'(a)
-// h and d are smooth, decay like a Gaussian and are fitted by degree-15 polynomials in s (tools/fit_gelu_poly.py:
-// max |error| 2.1e-6 for gelu and 7.7e-6 for gelu' over all x, the clamp included -- two to three orders below the
-// bf16 resolution of the values they are stored as).  17 full-rate FMAs per value, packed two per instruction.  NaN propagates through gelu (x enters the result arithmetically).
+// h and d are smooth, decay like a Gaussian and are fitted by degree-11 polynomials in s (tools/fit_gelu_poly.py:
+// max |error| 2.5e-5 for gelu and 7.5e-5 for gelu' over all x, the clamp included -- one to two orders below the
+// bf16 resolution of the values they are stored as, and below what the bf16 rounding of the pre-activation itself
+// does to them; degree 15 on [0, 5] reaches 2e-6 / 8e-6 for four more FMAs per value, which showed as 1-2 us per
+// K = 768 launch: the arithmetic of these epilogues is 7-10 us of a 75-110 us launch, measured by removing it).
+// 13 full-rate FMAs per value, packed two per instruction.  NaN propagates through gelu (x enters the result arithmetically).
 // (four values at a time: the two packed FMAs of a Horner step are independent, so the dependent chain of one never
 // waits on itself)
-__device__ __forceinline__ f32x4 gelu_poly15(f32x4 s, const float (&c)[16]) {
+template <int NC>
+__device__ __forceinline__ f32x4 gelu_poly(f32x4 s, const float (&c)[NC]) {
     f32x4 p = f32x4{c[0], c[0], c[0], c[0]};
 #pragma unroll
-    for (int i = 1; i < 16; ++i) p = __builtin_elementwise_fma(p, s, f32x4{c[i], c[i], c[i], c[i]});
+    for (int i = 1; i < NC; ++i) p = __builtin_elementwise_fma(p, s, f32x4{c[i], c[i], c[i], c[i]});
     return p;
 }
 __device__ __forceinline__ f32x4 gelu_arg(f32x4 ax) {
-    const f32x4 a = __builtin_elementwise_min(ax, f32x4{5.0f, 5.0f, 5.0f, 5.0f});
-    return __builtin_elementwise_fma(a, f32x4{0.4f, 0.4f, 0.4f, 0.4f}, f32x4{-1.0f, -1.0f, -1.0f, -1.0f});
+    const f32x4 a = __builtin_elementwise_min(ax, f32x4{4.5f, 4.5f, 4.5f, 4.5f});
+    constexpr float k = 2.0f / 4.5f;
+    return __builtin_elementwise_fma(a, f32x4{k, k, k, k}, f32x4{-1.0f, -1.0f, -1.0f, -1.0f});
 }
 __device__ __forceinline__ f32x4 gelu_erf(f32x4 x) {
-    constexpr float H[16] = {6.148313870e-03f, 9.584424711e-03f, -4.850091339e-02f, -2.617238834e-02f, 1.661755440e-01f,
-                             -4.678360634e-02f, -2.778284361e-01f, 3.142378781e-01f, 8.807269202e-02f, -4.799976110e-01f,
-                             4.167193239e-01f, -1.916992521e-02f, -2.567580210e-01f, 2.327782425e-01f, -9.402778579e-02f,
-                             1.552430374e-02f};
+    constexpr float H[12] = {1.300883733e-02f, -4.582281338e-02f, -1.295990111e-02f, 1.839340585e-01f, -1.427471890e-01f,
+                             -2.110001548e-01f, 4.206866235e-01f, -2.009975493e-01f, -1.448217540e-01f, 2.463749754e-01f,
+                             -1.331519655e-01f, 2.750082184e-02f};
     const f32x4 ax = __builtin_elementwise_abs(x);
-    const f32x4 h = gelu_poly15(gelu_arg(ax), H);
+    const f32x4 h = gelu_poly(gelu_arg(ax), H);
     return __builtin_elementwise_fma(f32x4{0.5f, 0.5f, 0.5f, 0.5f}, x + ax, -h);
 }
 __device__ __forceinline__ f32x4 gelu_erf_grad(f32x4 x) {
-    constexpr float D[16] = {-3.551303687e-02f, 3.686431968e-02f, 1.739708763e-01f, -2.521245251e-01f, -2.874238109e-01f,
-                             7.310743317e-01f, -7.726174418e-02f, -1.000123527e+00f, 9.660030973e-01f, 2.465856271e-01f,
-                             -1.144769890e+00f, 8.334412066e-01f, -3.124530075e-02f, -3.081097599e-01f, 1.862355296e-01f,
-                             -3.761111318e-02f};
-    const f32x4 d = gelu_poly15(gelu_arg(__builtin_elementwise_abs(x)), D);
+    constexpr float D[12] = {6.466877457e-02f, 5.175437277e-02f, -3.583151178e-01f, -2.645623924e-02f, 7.865651507e-01f,
+                             -4.628077661e-01f, -6.115162589e-01f, 9.403613011e-01f, -3.501445561e-01f, -1.936459407e-01f,
+                             2.187125727e-01f, -5.917018482e-02f};
+    const f32x4 d = gelu_poly(gelu_arg(__builtin_elementwise_abs(x)), D);
     const f32x4 half = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
     return half + __builtin_elementwise_copysign(half - d, x);
 }
