@@ -1457,7 +1457,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
 #pragma unroll
             for (int b = 0; b < 6; ++b) yf[b] = read_frag3<YKMAJ>(ly + (YKMAJ ? h * 4096 : 0), 6 * c + b, YKMAJ ? 0 : h, lane);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) xf[a] = read_frag3<XKMAJ>(lx + (XKMAJ ? h * 4096 : 0), 6 * r + a, XKMAJ ? 0 : h, lane);
+            for (int a = 0; a < 6; ++a)
+                xf[a] = read_frag3<XKMAJ>(lx + (XKMAJ ? h * 4096 : 0), 6 * r + (a + 3 * h) % 6, XKMAJ ? 0 : h, lane);
             stage_all(u + 2, nxt2);
             lds_fence(yf);
             lds_fence(xf);
@@ -1501,29 +1502,17 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
     char* flat = &lds[0][0];
     f32x4* mine = reinterpret_cast<f32x4*>(flat + wave * 18432) + lane;
     const f32x4* theirs = reinterpret_cast<const f32x4*>(flat + (wave ^ 4) * 18432) + lane;
-    if (h == 0) {
+    // (a wave of group 1 keeps its row fragments rotated by three -- xf[a] is fragment (a + 3) % 6 of the block -- so that
+    // for both groups acc[0..2] is the half that stays and acc[3..5] the half that goes: no register index depends on h)
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) mine[(a * 6 + b) * 64] = acc[3 + a][b];
-    } else {
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) mine[(a * 6 + b) * 64] = acc[a][b];
-    }
+        for (int b = 0; b < 6; ++b) mine[(a * 6 + b) * 64] = acc[3 + a][b];
     __builtin_amdgcn_s_barrier();
-    if (h == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) acc[a][b] += theirs[(a * 6 + b) * 64];
-    } else {
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) acc[a][b] = acc[3 + a][b] + theirs[(a * 6 + b) * 64];
-    }
+        for (int b = 0; b < 6; ++b) acc[a][b] += theirs[(a * 6 + b) * 64];
     f32x4 (&fin)[3][6] = reinterpret_cast<f32x4 (&)[3][6]>(acc);
     const int row0 = i0 + r * 96 + h * 48, col0 = j0 + c * 96;
     if constexpr (ROWSUM) {
@@ -1537,7 +1526,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
                 float v = rsv[a];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if (c == 0 && lane < 16) part[((h * 2 + r) * 6 + a) * 16 + lane] = v;
+                if (c == 0 && lane < 16) part[((h * 2 + r) * 6 + (a + 3 * h) % 6) * 16 + lane] = v;   // by block fragment
             }
             __builtin_amdgcn_s_barrier();
             if (h == 0 && c == 0 && lane < 16) {
