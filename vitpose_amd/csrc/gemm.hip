@@ -1504,17 +1504,21 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
     const f32x4* theirs = reinterpret_cast<const f32x4*>(flat + (wave ^ 4) * 18432) + lane;
     // (a wave of group 1 keeps its row fragments rotated by three -- xf[a] is fragment (a + 3) % 6 of the block -- so that
     // for both groups acc[0..2] is the half that stays and acc[3..5] the half that goes: no register index depends on h)
+    const int row0 = i0 + r * 96 + h * 48, col0 = j0 + c * 96;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 6; ++b) mine[(a * 6 + b) * 64] = acc[3 + a][b];
+    // the residual / position addend of the half that stays: requested now, into the registers the other half has just
+    // left, so that it arrives under the exchange
+    f32x4 pre[EPI == VP_EPI_RESID_F32 ? 3 : 1][6];
+    if constexpr (EPI == VP_EPI_RESID_F32) load_addend<3, 6>(e, pre, row0, col0, lane, M, N);
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 6; ++b) acc[a][b] += theirs[(a * 6 + b) * 64];
     f32x4 (&fin)[3][6] = reinterpret_cast<f32x4 (&)[3][6]>(acc);
-    const int row0 = i0 + r * 96 + h * 48, col0 = j0 + c * 96;
     if constexpr (ROWSUM) {
         if (do_rs) {                                 // (workgroup-uniform)
             __builtin_amdgcn_s_barrier();            // the exchange has been read
@@ -1545,7 +1549,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
             return;
         }
     }
-    run_epilogue<EPI, 3, 6>(e, fin, row0, col0, lane, M, N);
+    if constexpr (EPI == VP_EPI_RESID_F32) run_epilogue<EPI, 3, 6>(e, fin, row0, col0, lane, M, N, 0, pre);
+    else run_epilogue<EPI, 3, 6>(e, fin, row0, col0, lane, M, N);
 }
 
 

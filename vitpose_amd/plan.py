@@ -269,7 +269,10 @@ class Plan:
                     return f
                 modes = [1, 2, 3] if x_kmajor else ([1, 2, 3, 4] if split3 else [1, 2, 3, 4, 6])
                 if KSPLIT and not split3 and K >= 1536 and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_F32):
-                    modes.append(7)       # K tile split between the wave groups: pays for long reductions only
+                    # K tile split between the wave groups: pays for long reductions only.  (Its residual epilogue wins the
+                    # cache-hot timing done here -- fc2 + residual 55.3 against 58.9 us -- and loses inside the step, 50.5
+                    # against 49.4 us, and 2 % of the ViTPose-H evaluation pass: not offered for VP_EPI_RESID_F32.)
+                    modes.append(7)
                 if (not x_kmajor and not split3 and K >= 640 and M % 192 == 0 and row_map is None and colscale is None
                         and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_GELU, _lib.VP_EPI_DGELU)
                         and (M // 192) * ((N + 191) // 192) > 256):
