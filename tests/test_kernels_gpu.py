@@ -648,6 +648,47 @@ def test_gemm_ksplit_epilogues(dev):
                              epilogue=_lib.VP_EPI_F32, tile_mode=7))
 
 
+@pytest.mark.parametrize('mode,M,N,K,yk', [(6, 6144, 1024, 4096, False), (6, 6144, 1024, 3072, True),
+                                          (7, 12288, 768, 3072, False), (7, 12288, 768, 2304, True)])
+def test_gemm_new_schedules_at_model_sizes(dev, mode, M, N, K, yk):
+    """tile_mode 6 / 7 on the products they are chosen for (ViTPose-L N = 1024 at 6144 rows; ViTPose-B long reductions):
+    random data against an f32 matmul of the same bf16 operands, and bit-identical to the 192 x 192 schedule's output
+    wherever the summation order per output element is the same (mode 6; mode 7 adds its two halves last)."""
+    from vitpose_amd import _lib
+    X, W = rnd((M, K), dev, 21).bfloat16(), rnd((K, N) if yk else (N, K), dev, 22, 0.05).bfloat16()
+    ref = X.float() @ (W.float() if yk else W.float().t())
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    base = torch.empty_like(out)
+    run(lambda p: p.gemm(X, W, out, M, N, K, ldx=K, ldy=W.shape[1], ldo=N, y_kmajor=yk, epilogue=_lib.VP_EPI_BF16,
+                         tile_mode=mode))
+    run(lambda p: p.gemm(X, W, base, M, N, K, ldx=K, ldy=W.shape[1], ldo=N, y_kmajor=yk, epilogue=_lib.VP_EPI_BF16,
+                         tile_mode=3))
+    torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=2e-2)
+    if mode == 6:
+        assert torch.equal(out, base)
+    else:
+        torch.testing.assert_close(out.float(), base.float(), rtol=2 ** -6, atol=1e-2)   # a different f32 summation order: at most two bf16 steps
+
+
+def test_wgrad_grouped_ksplit_at_model_size(dev):
+    """The four Linear weight gradients of one ViTPose-B Block (64 images) on the K-split schedule, with the row sums of
+    qkv and fc1, against f32 matmuls."""
+    Kt, E = 12288, 768
+    shapes = [(3 * E, E, True), (E, E, False), (4 * E, E, True), (E, 4 * E, False)]
+    probs, refs = [], []
+    for i, (M, N, with_rs) in enumerate(shapes):
+        x, y = rnd((Kt, M), dev, 30 + 2 * i, 0.1).bfloat16(), rnd((Kt, N), dev, 31 + 2 * i, 0.1).bfloat16()
+        out = torch.full((M, N), float('nan'), device=dev)
+        rs = torch.full((M,), float('nan'), device=dev) if with_rs else None
+        probs.append((x, y, out, M, N, M, N, rs))
+        refs.append((x.float().t() @ y.float(), x.float().sum(0)))
+    run(lambda p: p.wgrad_group(probs, Kt, tile_mode=7))
+    for (x, y, out, *rest), (ref, rsum) in zip(probs, refs):
+        torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-2)
+        if rest[-1] is not None:
+            torch.testing.assert_close(rest[-1], rsum, rtol=1e-3, atol=1e-2)
+
+
 # ------------------------------------------------------------------ fp32-accurate path
 def to_pair(x):
     """Reference of the hi / lo pair layout: [R][K] f32 -> [R][2K] bf16, groups of 32 hi then their 32 lo."""
