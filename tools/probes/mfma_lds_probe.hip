@@ -133,6 +133,70 @@ __global__ __launch_bounds__(512, 2) void probe_ksplit(const bf16x8* __restrict_
     out[blockIdx.x * 512 + tid] = sum;
 }
 
+// mode 7: the 96 x 48 wave tile of mode 4 with BOTH sub-steps of a K tile in one interval: 18 fragment reads and 6 LDS-DMA
+// loads per 36 MFMAs, two barriers per 36 MFMAs (same LDS traffic as mode 4, half the barriers, intervals twice as long).
+__global__ __launch_bounds__(512, 2) void probe_long(const bf16x8* __restrict__ in, float* out, int iters, const char* gsrc,
+                                                     size_t gspan) {
+    __shared__ __attribute__((aligned(16))) char lds[147456];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 147456 / 16; i += 512) reinterpret_cast<bf16x8*>(lds)[i] = in[i & 4095];
+    __syncthreads();
+    bf16x8 a[6][2], b[3][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i][s] = in[(tid * 18 + s * 9 + i) & 4095];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i][s] = in[(tid * 18 + s * 9 + 6 + i) & 4095];
+    }
+    f32x4 acc[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* base = lds + (wave & 3) * 9216 + lane * 16;
+    if (wave >= 4) __builtin_amdgcn_s_barrier();
+    size_t goff = ((size_t)blockIdx.x * 8 + wave) * 6144 + lane * 16;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        const char* p = base + (it % 3) * 49152;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a[i][s] = *reinterpret_cast<const bf16x8*>(p + s * 36864 % 40000 + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) b[i][s] = *reinterpret_cast<const bf16x8*>(p + s * 36864 % 40000 + (6 + i) * 1024);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + goff + k * 1024),
+                                             (__attribute__((address_space(3))) void*)(lds + ((it + 2) % 3) * 49152 + (wave * 6 + k) * 1024), 16, 0, 0);
+        }
+        goff += (size_t)256 * 8 * 6144;
+        if (goff >= gspan) goff -= gspan;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][s], a[i][s], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sum += acc[i][j][0] + acc[i][j][3];
+    out[blockIdx.x * 512 + tid] = sum;
+}
+
 int main() {
     const int n = 4096 * 8;
     std::vector<unsigned short> h(n);
@@ -151,7 +215,7 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000, grid = 256;
-    for (int mode = 0; mode < 7; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
         float best = 1e30f, last = 0.f;
         for (int rep = 0; rep < 60; ++rep) {
             hipEventRecord(e0);
@@ -162,7 +226,8 @@ int main() {
                 case 3: probe<3><<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters, (const char*)gbig, l2span); break;
                 case 4: probe<4><<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters, (const char*)gbig, l2span); break;
                 case 5: probe<4><<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters, (const char*)gbig, big - ((size_t)64 << 20)); break;
-                default: probe_ksplit<<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters / 2, (const char*)gbig, l2span); break;
+                case 6: probe_ksplit<<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters / 2, (const char*)gbig, l2span); break;
+                default: probe_long<<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters / 2, (const char*)gbig, l2span); break;
             }
             hipEventRecord(e1);
             hipEventSynchronize(e1);
