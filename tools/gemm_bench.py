@@ -24,55 +24,59 @@ def main():
                     '5 = persistent 192x192, 6 = 192x128 with one workgroup per CU')
     ap.add_argument('--group-blocks', type=int, default=4)
     ap.add_argument('--wsplit', type=int, default=0, help='override the wgrad K split')
+    ap.add_argument('--pad', type=int, default=0, help='pad every bf16 operand row by this many elements (row stride no '
+                    'longer a multiple of the memory-channel interleave)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     M, E = args.tokens, args.embed
     g = torch.Generator().manual_seed(0)
 
-    def rb(*s):
-        return (torch.rand(*s, generator=g) * 2 - 1).to(dev).bfloat16()
+    P = args.pad
+
+    def rb(r, c):
+        return (torch.rand(r, c + P, generator=g) * 2 - 1).to(dev).bfloat16()
     cases = []
     for name, N, K in (('qkv', 3 * E, E), ('proj', E, E), ('fc1', 4 * E, E), ('fc2', E, 4 * E)):
         x, w = rb(M, K), rb(N, K)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         cases.append((f'fwd_{name}   M{M} N{N} K{K}', 2.0 * M * N * K,
-                      lambda p, x=x, w=w, out=out, N=N, K=K: p.gemm(x, w, out, M, N, K, ldx=K, ldy=K, ldo=N,
+                      lambda p, x=x, w=w, out=out, N=N, K=K: p.gemm(x, w, out, M, N, K, ldx=K + P, ldy=K + P, ldo=N,
                                                                        tile_mode=args.tile_mode)))
         dy = rb(M, N)
         dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
         cases.append((f'dgrad_{name} M{M} N{K} K{N}', 2.0 * M * N * K,
-                      lambda p, dy=dy, w=w, dx=dx, N=N, K=K: p.gemm(dy, w, dx, M, K, N, ldx=N, ldy=K, ldo=K,
+                      lambda p, dy=dy, w=w, dx=dx, N=N, K=K: p.gemm(dy, w, dx, M, K, N, ldx=N + P, ldy=K + P, ldo=K,
                                                                     y_kmajor=True, tile_mode=args.tile_mode)))
         if name == 'fc1':
             u2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             bias = torch.zeros(N, device=dev)
             cases.append((f'fwd_fc1+GELU M{M} N{N} K{K}', 2.0 * M * N * K,
                           lambda p, x=x, w=w, out=out, u2=u2, bias=bias, N=N, K=K: p.gemm(
-                              x, w, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, out2=u2,
+                              x, w, out, M, N, K, ldx=K + P, ldy=K + P, ldo=N, bias=bias, out2=u2,
                               epilogue=_lib.VP_EPI_GELU, tile_mode=args.tile_mode)))
         if name == 'fc2':
             aux = rb(M, K)
             cases.append((f'dgrad_fc2+DGELU M{M} N{K} K{N}', 2.0 * M * N * K,
                           lambda p, dy=dy, w=w, dx=dx, aux=aux, N=N, K=K: p.gemm(
-                              dy, w, dx, M, K, N, ldx=N, ldy=K, ldo=K, y_kmajor=True, epilogue=_lib.VP_EPI_DGELU,
-                              aux=aux, ldaux=K, tile_mode=args.tile_mode)))
+                              dy, w, dx, M, K, N, ldx=N + P, ldy=K + P, ldo=K, y_kmajor=True, epilogue=_lib.VP_EPI_DGELU,
+                              aux=aux, ldaux=K + P, tile_mode=args.tile_mode)))
             r32, o32 = torch.zeros(M, N, device=dev), torch.empty(M, N, device=dev)
             bias2 = torch.zeros(N, device=dev)
             cases.append((f'fwd_fc2+RESID M{M} N{N} K{K}', 2.0 * M * N * K,
                           lambda p, x=x, w=w, o32=o32, r32=r32, bias2=bias2, N=N, K=K: p.gemm(
-                              x, w, o32, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias2, resid=r32,
+                              x, w, o32, M, N, K, ldx=K + P, ldy=K + P, ldo=N, bias=bias2, resid=r32,
                               epilogue=_lib.VP_EPI_RESID_F32, tile_mode=args.tile_mode)))
         dw = torch.empty(N, K, device=dev)
         slab = torch.empty(_slab_elems(N * K, M), device=dev)
         sk = args.wsplit or _split_k(N, K, M)
         cases.append((f'wgrad_{name} M{N} N{K} K{M} split{sk}', 2.0 * M * N * K,
                       lambda p, dy=dy, x=x, dw=dw, slab=slab, N=N, K=K, sk=sk: p.wgrad(
-                          dy, x, dw, N, K, M, ldx=N, ldy=K, split_k=sk, slab=slab, tile_mode=args.tile_mode)))
+                          dy, x, dw, N, K, M, ldx=N + P, ldy=K + P, split_k=sk, slab=slab, tile_mode=args.tile_mode)))
     # grouped: the four Linear weight gradients of `--group-blocks` Blocks in one launch, no K split
     probs = []
     for blk in range(args.group_blocks):
         for N, K in ((3 * E, E), (E, E), (4 * E, E), (E, 4 * E)):
-            probs.append((rb(M, N), rb(M, K), torch.empty(N, K, device=dev), N, K, N, K))
+            probs.append((rb(M, N), rb(M, K), torch.empty(N, K, device=dev), N, K, N + P, K + P))
     gflops = sum(2.0 * M * p[3] * p[4] for p in probs)
     cases.append((f'wgrad_group {args.group_blocks} blocks ({len(probs)} problems)', gflops,
                   lambda p: p.wgrad_group(probs, M, tile_mode=args.tile_mode if args.tile_mode in (2, 3, 7) else 0)))

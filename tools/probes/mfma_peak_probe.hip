@@ -13,8 +13,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int SHAPE>
-__global__ __launch_bounds__(512, 2) void probe(const bf16x8* __restrict__ in, float* out, int iters) {
+__global__ __launch_bounds__(512, 2) void probe(const bf16x8* __restrict__ in, float* out, int iters, long long* clk) {
     const int tid = threadIdx.x;
+    const long long c0 = clock64(), w0 = wall_clock64();   // shader clock / constant 100 MHz counter
     bf16x8 a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -64,6 +65,10 @@ __global__ __launch_bounds__(512, 2) void probe(const bf16x8* __restrict__ in, f
             for (int j = 0; j < 2; ++j) sum += acc[i][j][0] + acc[i][j][15];
     }
     out[blockIdx.x * 512 + tid] = sum;
+    if (blockIdx.x == 0 && tid == 0) {
+        clk[0] = clock64() - c0;
+        clk[1] = wall_clock64() - w0;
+    }
 }
 
 int main() {
@@ -78,6 +83,10 @@ int main() {
     void *din, *dout;
     hipMalloc(&din, n * 2);
     hipMalloc(&dout, 1024 * 512 * 4);
+    long long* dclk;
+    hipMalloc((void**)&dclk, 16);
+    int wall_khz = 0;
+    hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int zero = 0; zero < 2; ++zero) {
@@ -86,14 +95,20 @@ int main() {
             for (int rep = 0; rep < 240; ++rep) {
                 const int iters = 40000, grid = 256;
                 hipEventRecord(e0);
-                if (shape == 16) probe<16><<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters);
-                else probe<32><<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters);
+                if (shape == 16) probe<16><<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters, dclk);
+                else probe<32><<<grid, 512>>>((const bf16x8*)din, (float*)dout, iters, dclk);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 // per wave per iter: 16 MFMAs of 16384 flop (16x16x32) or 8 of 32768 (32x32x16)
                 double flop = (double)grid * 8 * iters * 16 * 16384.0;
-                if (rep % 40 == 39 || rep < 2) printf("%s data, %dx%d rep %d: %.2f ms  %.0f TFLOP/s\n", zero ? "zero" : "random", shape, shape, rep, ms, flop / ms / 1e9);
+                if (rep % 40 == 39 || rep < 2) {
+                    long long hc[2];
+                    hipMemcpy(hc, dclk, 16, hipMemcpyDeviceToHost);
+                    // core clock the loop ran at = shader-clock ticks per tick of the constant-rate counter
+                    printf("%s data, %dx%d rep %d: %.2f ms  %.0f TFLOP/s  core clock %.0f MHz\n", zero ? "zero" : "random", shape,
+                           shape, rep, ms, flop / ms / 1e9, (double)hc[0] / (double)hc[1] * wall_khz / 1e3);
+                }
             }
         }
     }

@@ -4,8 +4,49 @@
 //   B operand: lane l holds B[k = 8*(l>>4) + 0..7][col l&15]
 //   C/D:       lane l holds D[row 4*(l>>4) + r][col l&15], r = 0..3
 #pragma once
+
+// Clock probe builds.  -DVP_CLOCK_PROBE=1: lane 0 of workgroup 0 prints the shader-clock and the constant-rate (100 MHz)
+// counter over a kernel's K loop, i.e. the core clock the loop actually ran at.  -DVP_CLOCK_PROBE=2: lane 0 of EVERY
+// workgroup records (vp_tile_log, read back with vp_probe_dump) where it ran (XCC id, hardware id) and the constant-rate counter at its start, at the end of its K
+// loop and after its last store has been acknowledged: the timeline of a launch, tile by tile.  Empty in the product build.
+#if defined(VP_CLOCK_PROBE) && VP_CLOCK_PROBE == 2
+#define VP_CLK_BEGIN() const long long vp_wall0 = wall_clock64(); long long vp_wallk = 0
+#define VP_CLK_END(name) vp_wallk = wall_clock64()
+#define VP_CLK_FINAL(name, tile)                                                                              \
+    do {                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < VP_TILE_LOG_MAX) {                                               \
+            long long* vp_r = vp_tile_log + (size_t)blockIdx.x * 8;                                           \
+            vp_r[0] = (long long)(tile);                                                                      \
+            vp_r[1] = nk;                                                                                     \
+            vp_r[2] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                             \
+            vp_r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                              \
+            vp_r[4] = vp_wall0;                                                                               \
+            vp_r[5] = vp_wallk;                                                                               \
+            vp_r[6] = wall_clock64();                                                                         \
+        }                                                                                                     \
+    } while (0)
+#elif defined(VP_CLOCK_PROBE)
+#define VP_CLK_BEGIN() const long long vp_clk0 = clock64(), vp_wall0 = wall_clock64()
+#define VP_CLK_END(name)                                                                                      \
+    do {                                                                                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                                              \
+            printf("clkprobe %s nk %d shader %lld wall %lld\n", name, nk, clock64() - vp_clk0, wall_clock64() - vp_wall0); \
+    } while (0)
+#define VP_CLK_FINAL(name, tile) do {} while (0)
+#else
+#define VP_CLK_BEGIN() do {} while (0)
+#define VP_CLK_END(name) do {} while (0)
+#define VP_CLK_FINAL(name, tile) do {} while (0)
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#if defined(VP_CLOCK_PROBE) && VP_CLOCK_PROBE == 2
+constexpr int VP_TILE_LOG_MAX = 8192;
+static __device__ long long vp_tile_log[VP_TILE_LOG_MAX * 8];   // one record of eight words per workgroup of the last launch
+#endif
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -1085,12 +1085,18 @@ __device__ __forceinline__ void stage_unit(const Operand& op, int r0, int k0, ch
         const int r = L >> 3, c = (L & 7) ^ (r & 7);
         int row = r0 + r;
         row = row < op.rows ? row : op.rows - 1;
+#ifdef VP_ABLATE_SAMETILE
+        row %= 192;          // ablation build: every tile reads the operand rows of tile 0 (results wrong; operands L2-resident)
+#endif
         src = op.p + (size_t)row * op.ld + k0 + c * 8;
     } else {             // [64 k rows][64 columns], 32-byte units XOR-swizzled for the transposed read
         const int kr = L >> 3, s16 = L & 7;
         const int unit = (s16 >> 1) ^ kmaj64_key(kr);
         int col = r0 + (unit * 2 + (s16 & 1)) * 8;
         col = col <= op.rows - 8 ? col : op.rows - 8;
+#ifdef VP_ABLATE_SAMETILE
+        col %= 192;
+#endif
         src = op.p + (size_t)(k0 + kr) * op.ld + col;
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -1192,6 +1198,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     const int kt0 = slice * ksplit_tiles;
     const int kt1 = min(nk_all, kt0 + ksplit_tiles);
     int nk = kt1 - kt0;
+    VP_CLK_BEGIN();
     // image iterator of a masked problem: `mcur` = unvisited bits of mask word `mword`, (mimg, msub) = position
     const unsigned long long* mwords = nullptr;
     unsigned long long mcur = 0;
@@ -1361,11 +1368,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             k_loop(std::false_type{});
         }
     }
+    VP_CLK_END("gemm192");
     if constexpr (epi_is_bf16<EPI>()) {
         if (((N | e.ldo) & 7) == 0) {
             __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free for staging
             run_epilogue_staged<EPI, 6, NU, 3>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N,
                                                &lds[0][0] + wave * (48 * (NU * 32 + 16)));
+            VP_CLK_FINAL("gemm192", work);
             return;
         }
     }
@@ -1379,6 +1388,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
         run_epilogue<EPI, 6, NU>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, slice, pre);
     else
         run_epilogue<EPI, 6, NU>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, slice);
+    VP_CLK_FINAL("gemm192", work);
 }
 
 
@@ -1415,6 +1425,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
     const int gm = min(tiles_m - gid * 8, 8);
     const int i0 = (gid * 8 + tin % gm) * T3, j0 = (tin / gm) * T3;
     const int nk = K / BK;
+    VP_CLK_BEGIN();
 
     f32x4 acc[6][6];
 #pragma unroll
@@ -1498,6 +1509,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
     }
     // ---- the two sub-step halves meet: wave (0, q) keeps rows 0-47 of its block, wave (1, q) rows 48-95; each hands the
     // other half (18 fragments, 1 KiB each, lane-linear) to its partner through LDS
+    VP_CLK_END("gemm192k");
     __builtin_amdgcn_s_barrier();                    // every wave's loads have landed and every read of the stages is done
     char* flat = &lds[0][0];
     f32x4* mine = reinterpret_cast<f32x4*>(flat + wave * 18432) + lane;
@@ -1551,6 +1563,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192k_kernel(Operand X, Oper
     }
     if constexpr (EPI == VP_EPI_RESID_F32) run_epilogue<EPI, 3, 6>(e, fin, row0, col0, lane, M, N, 0, pre);
     else run_epilogue<EPI, 3, 6>(e, fin, row0, col0, lane, M, N);
+    VP_CLK_FINAL("gemm192k", work);
 }
 
 
@@ -2169,6 +2182,13 @@ extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
 }
 
 static int group_tile(int tile_mode) { return tile_mode == 2 ? T2 : T3; }
+
+#if defined(VP_CLOCK_PROBE) && VP_CLOCK_PROBE == 2
+// probe build only: the per-workgroup records of the last launch of an instrumented kernel
+extern "C" int vp_probe_dump(long long* host, int words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vp_tile_log), (size_t)words * 8);
+}
+#endif
 
 extern "C" int vp_wgrad_group_table(vp_group_entry* problems, int count, int tile_mode, int* total_tiles) {
     VP_CHECK_ARG(problems && total_tiles && count > 0 && count <= 64 && (tile_mode == 2 || tile_mode == 3 || tile_mode == 7));
