@@ -302,16 +302,20 @@ __global__ __launch_bounds__(256) void sumsq_chunks_partial_kernel(const float* 
                                                                    const long* __restrict__ chunk_start,
                                                                    const int* __restrict__ chunk_len, int nchunks,
                                                                    float* __restrict__ partial) {
-    float s = 0.f;
+    // two loads in flight per lane and pass (independent partial sums, combined in a fixed order)
+    float s0 = 0.f, s1 = 0.f;
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const float* p = x + chunk_start[c];
         const int len = chunk_len[c];
-        for (int i = threadIdx.x * 4; i < len; i += 256 * 4) {
+        for (int i = threadIdx.x * 4; i < len; i += 2 * 256 * 4) {
+            const int i2 = i + 256 * 4;
             const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
-            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            const f32x4 w = i2 < len ? *reinterpret_cast<const f32x4*>(p + i2) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s0 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            s1 += w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
         }
     }
-    s = wave_sum(s);
+    float s = wave_sum(s0 + s1);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -528,12 +532,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         clip *= fminf(1.f, max_norm / (tn + 1e-6f));
     }
     const float step = lr_c / bc1;
-    for (int i = threadIdx.x * 4; i < len; i += 256 * 4) {
-        const long o = s0 + i;
-        f32x4 pv = *reinterpret_cast<f32x4*>(p + o);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o) * clip;
-        f32x4 mv = *reinterpret_cast<f32x4*>(m + o);
-        f32x4 vv = *reinterpret_cast<f32x4*>(v + o);
+    auto update = [&](long o, f32x4 pv, f32x4 gv, f32x4 mv, f32x4 vv) {
+        gv *= clip;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             pv[r] *= 1.f - lr_c * wd;
@@ -545,6 +545,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         *reinterpret_cast<f32x4*>(m + o) = mv;
         *reinterpret_cast<f32x4*>(v + o) = vv;
         if (p_bf16) *reinterpret_cast<bf16x4*>(p_bf16 + o) = pack4(pv[0], pv[1], pv[2], pv[3]);
+    };
+    // two float4 per lane and pass: all eight loads are issued before the first store
+    for (int i = threadIdx.x * 4; i < len; i += 2 * 256 * 4) {
+        const long o = s0 + i, o2 = o + 256 * 4;
+        const bool two = i + 256 * 4 < len;
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(p + o), ga = *reinterpret_cast<const f32x4*>(g + o);
+        const f32x4 ma = *reinterpret_cast<const f32x4*>(m + o), va = *reinterpret_cast<const f32x4*>(v + o);
+        f32x4 pb = pa, gb = ga, mb = ma, vb = va;
+        if (two) {
+            pb = *reinterpret_cast<const f32x4*>(p + o2);
+            gb = *reinterpret_cast<const f32x4*>(g + o2);
+            mb = *reinterpret_cast<const f32x4*>(m + o2);
+            vb = *reinterpret_cast<const f32x4*>(v + o2);
+        }
+        update(o, pa, ga, ma, va);
+        if (two) update(o2, pb, gb, mb, vb);
     }
 }
 
@@ -738,7 +754,7 @@ extern "C" int vp_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t s
 extern "C" int vp_sumsq_chunks_det(const float* x, const long* chunk_start, const int* chunk_len, int nchunks, float* out,
                                    float* partials, int npartials, hipStream_t stream) {
     VP_CHECK_ARG(x && chunk_start && chunk_len && nchunks > 0 && out && partials && npartials >= 1);
-    int blocks = npartials < 1024 ? npartials : 1024;
+    int blocks = npartials < 2048 ? npartials : 2048;      // eight 256-thread workgroups per CU
     if (blocks > nchunks) blocks = nchunks;
     hipLaunchKernelGGL(sumsq_chunks_partial_kernel, dim3(blocks), dim3(256), 0, stream, x, chunk_start, chunk_len, nchunks,
                        partials);

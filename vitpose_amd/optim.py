@@ -84,7 +84,7 @@ class FlatAdamW:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         # per-workgroup partial sums of the gradient norm: summed in a fixed order, so that every data-parallel
         # replica derives the same clip factor, bit for bit, from the same all-reduced gradients
-        self.gnorm_partials = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.gnorm_partials = torch.zeros(2048, dtype=torch.float32, device=dev)
 
     def step(self, lr: float = None, grad_scale: float = 1.0):
         from . import _lib
