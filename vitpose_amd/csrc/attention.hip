@@ -223,6 +223,7 @@ __global__ __launch_bounds__(768, 1) void attn_bwd_kernel(const bf16* __restrict
     float* s_del = s_lse + NTOK;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    VP_TLOG(0);
     int b, h;
     image_head<D>(blockIdx.x, gridDim.x, H, b, h);
     const size_t ld = 3 * (size_t)E;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(768, 1) void attn_bwd_kernel(const bf16* __restrict
         }
     }
     __syncthreads();
+    VP_TLOG(1);
     const float c = scale * LOG2E;
     bf16* dq_base = dqkv + (size_t)b * NTOK * ld + h * D;
 
@@ -346,6 +348,11 @@ __global__ __launch_bounds__(768, 1) void attn_bwd_kernel(const bf16* __restrict
             }
         }
     }
+#if defined(VP_CLOCK_PROBE) && VP_CLOCK_PROBE == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (probe build: the stamp is taken when the wave's stores are acknowledged)
+    if (wave == 0) VP_TLOG(2);
+    if (threadIdx.x == 6 * 64 && blockIdx.x < VP_TILE_LOG_MAX) vp_tile_log[(size_t)blockIdx.x * 8 + 3] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -518,6 +525,13 @@ extern "C" int vp_attention_fwd(const void* qkv, void* out, float* lse, int B, i
     }
     VP_LAUNCH_RET();
 }
+
+#if defined(VP_CLOCK_PROBE) && VP_CLOCK_PROBE == 2
+// probe build only: the per-workgroup time stamps of the last instrumented attention launch
+extern "C" int vp_probe_dump_attn(long long* host, int words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vp_tile_log), (size_t)words * 8);
+}
+#endif
 
 extern "C" int vp_attention_bwd(const void* qkv, const void* out_fwd, const void* dout, const float* lse, void* dqkv,
                                 int B, int H, int head_dim, int tokens, float scale, hipStream_t stream) {

@@ -26,7 +26,13 @@
             vp_r[6] = wall_clock64();                                                                         \
         }                                                                                                     \
     } while (0)
+// generic per-workgroup time stamps (words 0..7 of the workgroup's record)
+#define VP_TLOG(slot)                                                                                        \
+    do {                                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < VP_TILE_LOG_MAX) vp_tile_log[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    } while (0)
 #elif defined(VP_CLOCK_PROBE)
+#define VP_TLOG(slot) do {} while (0)
 #define VP_CLK_BEGIN() const long long vp_clk0 = clock64(), vp_wall0 = wall_clock64()
 #define VP_CLK_END(name)                                                                                      \
     do {                                                                                                      \
@@ -35,6 +41,7 @@
     } while (0)
 #define VP_CLK_FINAL(name, tile) do {} while (0)
 #else
+#define VP_TLOG(slot) do {} while (0)
 #define VP_CLK_BEGIN() do {} while (0)
 #define VP_CLK_END(name) do {} while (0)
 #define VP_CLK_FINAL(name, tile) do {} while (0)
