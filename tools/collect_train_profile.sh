@@ -1,5 +1,5 @@
 set -e
-OUT=gpurun_out/r2e; TAG=r02_e
+OUT=gpurun_out/${TAG_DIR:-r2f}; TAG=${TAG:-r02_f}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 name=train_B; steps=20; warm=5
