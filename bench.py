@@ -239,9 +239,18 @@ def main():
                  paramwise_cfg=dict(num_layers=m['depth'], layer_decay_rate=m['layer_decay'])),
             grad_clip=dict(max_norm=1., norm_type=2))
         comm = None
-        if world > 1:
+        # VITPOSE_BENCH_FORCE_DDP=1 (rehearsal on one GPU, never set by the driver): a one-rank RCCL group with the bucketed
+        # plan of N > 1 and every collective launched (a sum over one rank) -- what the bucket structure itself costs
+        force_ddp = world == 1 and os.environ.get('VITPOSE_BENCH_FORCE_DDP', '0') == '1'
+        if force_ddp:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        if world > 1 or force_ddp:
             comm = model.enable_ddp()
             comm.measure = True        # event pairs around the end-of-backward wait: exposed vs hidden all-reduce time
+            if force_ddp:
+                comm.world = 2         # launches the all-reduces (and halves the gradients: a rehearsal of the schedule only)
 
         def step():
             losses = model.forward_train(img, target, tw, metas)
@@ -378,7 +387,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_batch, args.mode)
             out.update(parity_vs_oracle(eng, args.model, args.cpu_batch, dev))
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
