@@ -156,16 +156,42 @@ def cpu_baseline(model_key, batch, mode, iters=None):
                        f'the CPU share of this job ({visible} logical CPUs visible on the machine)')
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, written by tools/pmc_traffic.py), or None."""
+def pmc_traffic(kernel_key, flop_per_launch):
+    """(HBM bytes per launch, where the figure comes from) for the dominant kernel.  The bytes are counters of an
+    earlier profiling run of this command (rocprofv3 --pmc passes cannot run inside the bench), committed as
+    profiles/pmc_traffic.json by tools/pmc_traffic.py together with the tree state and launch size they were taken
+    on; a record taken on a launch of a different size does not describe this run and gives (None, reason)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if not os.path.exists(path):
-        return None
+        return None, 'profiles/pmc_traffic.json not found'
     try:
-        return json.load(open(path)).get(kernel_key, {}).get('hbm_bytes_per_launch')
-    except (OSError, ValueError):
-        return None
+        d = json.load(open(path))
+    except (OSError, ValueError) as e:
+        return None, f'profiles/pmc_traffic.json unreadable: {e}'
+    rec = d.get(kernel_key)
+    if not rec:
+        return None, f'profiles/pmc_traffic.json has no record for {kernel_key}'
+    src = f"profiles/pmc_traffic.json (state {d.get('_state', '?')}, {d.get('_source', 'rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ passes')})"
+    want = rec.get('gflop_per_launch')
+    if want is not None and abs(want - flop_per_launch / 1e9) > 0.01 * want:
+        return None, src + f": taken on launches of {want} GFLOP, this run's are {flop_per_launch / 1e9:.1f}"
+    return rec.get('hbm_bytes_per_launch'), src
+
+
+def launch_ranks(n):
+    """Start `n` ranks of this script (one process per GPU) the way the reference's tools/dist_train.sh:16-21 does,
+    with torch.distributed.run on 127.0.0.1 and a free port; returns the launcher's exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs between processes on these hosts
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -188,12 +214,16 @@ def main():
     if os.environ.get('VITPOSE_BENCH_WATCHDOG'):        # debugging aid: dump every thread's stack and exit when stuck
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['VITPOSE_BENCH_WATCHDOG']), exit=True)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has not touched a GPU yet (importing torch does not) and never
+        # will -- it starts the N ranks as fresh child processes through torch.distributed.run, lets their output
+        # through (rank 0 prints the JSON line) and exits with their status
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)')
     # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks: VITPOSE_BENCH_SHARE_GPU=1 lets the ranks share
     # the GPUs that exist and VITPOSE_BENCH_BACKEND=gloo carries the collectives between them (RCCL refuses two ranks
     # on one device).  The numbers of such a run mean nothing; the driver never sets either variable.
@@ -329,10 +359,62 @@ def main():
     comm_ms = comm.exposed_ms() if args.mode == 'train' and comm is not None else []
     plan_of().timers = None
     plan_of().timer_filter = None
+    rank_info = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        # what the collective library itself reports: a sum of ones over the group = the number of ranks that took
+        # part; every rank's median step time (ranks tune their tile schedules independently: skew shows here)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        mine = torch.tensor([step_ms[len(step_ms) // 2]], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(float(e.item()), 3) for e in every]
+        rank_info = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                     'allreduce_of_ones': int(ones.item()), 'step_ms_median_per_rank': per_rank,
+                     'step_ms_rank_min': min(per_rank), 'step_ms_rank_max': max(per_rank),
+                     'env': {k: os.environ.get(k) for k in ('NCCL_MAX_NCHANNELS', 'NCCL_MIN_NCHANNELS', 'NCCL_ALGO',
+                                                            'NCCL_PROTO', 'VITPOSE_DDP_BF16', 'VITPOSE_WGRAD_GROUP',
+                                                            'TORCH_NCCL_BLOCKING_WAIT')}}
+
+    # The reference's default iteration (second figure): BasePose.train_step (detectors/base.py:78-113) with the PCK
+    # accuracy of every iteration (topdown_heatmap_simple_head.py:170-195) and the logged scalars reduced over ranks
+    # and read on the host (_parse_losses, base.py:38-76) -- what a user gets without `train_cfg.skip_accuracy`.
+    default_iter = None
+    if args.mode == 'train' and not args.plus:
+        model.train_cfg['skip_accuracy'] = False
+        batch = dict(img=img, target=target, target_weight=tw, img_metas=metas)
+
+        def ref_step():
+            out = model.train_step(batch, None)
+            out['loss'].backward()
+            opt.step()
+            opt.zero_grad()
+            return out
+        for _ in range(2):
+            ref_out = ref_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            ref_out = ref_step()
+        torch.cuda.synchronize()
+        rdt = time.perf_counter() - r0
+        if world > 1:
+            t = torch.tensor([rdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rdt = t.item()
+        model.train_cfg['skip_accuracy'] = True
+        default_iter = {'images_per_sec': round(world * B * args.steps / rdt, 2),
+                        'ms_per_step': round(rdt / args.steps * 1e3, 3),
+                        'log_vars': {k: round(float(v), 6) for k, v in ref_out['log_vars'].items()},
+                        'note': 'model.train_step per iteration: forward_train WITH get_accuracy (device arg-max, '
+                                '[B,17] indices to the host) + _parse_losses (one collective for all logged scalars, one '
+                                'host read) + backward + clip + AdamW; the headline value is the same step without the '
+                                'per-iteration accuracy and host read (train_cfg.skip_accuracy)'}
 
     groups = all_groups
     tot_t = sum(d[0] for d in groups.values())
@@ -346,6 +428,7 @@ def main():
         kname = f'vp_gemm_bf16<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi % 100}>'
         if epi == 100:   # the grouped launcher runs gemm192_kernel / gemm256_kernel<true, true, VP_EPI_F32>
             kname = 'vp_wgrad_grouped_bf16'
+        traffic, traffic_src = pmc_traffic(kname, dflop / dn)
         out = {
             'metric': 'images/sec (256x192) ViTPose-B fwd+bwd at 1/2/4/8 GPUs; % bf16 MFMA roofline',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
@@ -360,7 +443,8 @@ def main():
             'roofline': {
                 'bound': 'mfma', 'kernel': f'{kname} ({EPI_NAMES[epi]})',
                 'achieved': round(dflop / dsec / 1e12, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(dflop / dsec / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic(kname),
+                'frac': round(dflop / dsec / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                'traffic_source': traffic_src,
                 'launches': dn, 'avg_launch_us': round(dsec / dn * 1e6, 2),
                 'algorithmic_gflop_per_launch': round(dflop / dn / 1e9, 3),
                 'share_of_step_time': round(dsec / dt, 3),
@@ -374,6 +458,10 @@ def main():
         }
         if args.mode == 'train':
             out['loss'] = float(last.item())
+        if default_iter is not None:
+            out['reference_default_iteration'] = default_iter
+        if rank_info is not None:
+            out['ranks'] = rank_info
         if comm_ms:
             ex, busy = sorted(e for e, _ in comm_ms), sorted(b for _, b in comm_ms)
             out['allreduce'] = {

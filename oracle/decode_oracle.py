@@ -141,20 +141,28 @@ def keypoints_from_heatmaps(heatmaps, center, scale, post_process='default', ker
 def combined_target_decode(heatmaps, center, scale, kernel=11, valid_radius_factor=0.0546875, image_space=True):
     """UDP decoding of 'CombinedTarget' maps (top_down_eval.py:571-585): three maps per joint (heat, x offset,
     y offset); the heat map is blurred with 2 * kernel + 1 taps, the offsets with `kernel` taps; the arg-max of the
-    blurred heat map is moved by valid_radius_factor * H times the blurred offsets at that pixel."""
+    blurred heat map is moved by valid_radius_factor * H times the blurred offsets at that pixel.  The offsets are
+    looked up the way the reference does it, in the FLATTENED offset maps of the whole batch at index
+    x + y * W + W * H * j: a joint without a positive maximum has (x, y) = (-1, -1), which lands on pixel
+    (H - 2, W - 1) of the previous joint's maps (and, for j = 0, wraps to the last joint: a negative numpy index)."""
     N, C, H, W = heatmaps.shape
     K = C // 3
-    preds = np.zeros((N, K, 2), dtype=np.float32)
-    maxvals = np.zeros((N, K, 1), dtype=np.float32)
     radius = np.float32(valid_radius_factor * H)
+    hm = np.zeros((N, K, H, W), dtype=np.float32)
+    ox, oy = np.zeros_like(hm), np.zeros_like(hm)
     for n in range(N):
         for k in range(K):
-            hm = blur(heatmaps[n, 3 * k].astype(np.float32), 2 * kernel + 1)
-            ox = blur(heatmaps[n, 3 * k + 1].astype(np.float32), kernel)
-            oy = blur(heatmaps[n, 3 * k + 2].astype(np.float32), kernel)
-            c, v = max_pred(hm)
-            x, y = int(c[0]), int(c[1])
-            c = c + np.array([ox[y, x] * radius, oy[y, x] * radius], dtype=np.float32)
+            hm[n, k] = blur(heatmaps[n, 3 * k].astype(np.float32), 2 * kernel + 1)
+            ox[n, k] = blur(heatmaps[n, 3 * k + 1].astype(np.float32), kernel)
+            oy[n, k] = blur(heatmaps[n, 3 * k + 2].astype(np.float32), kernel)
+    ox, oy = ox.reshape(-1) * radius, oy.reshape(-1) * radius
+    preds = np.zeros((N, K, 2), dtype=np.float32)
+    maxvals = np.zeros((N, K, 1), dtype=np.float32)
+    for n in range(N):
+        for k in range(K):
+            c, v = max_pred(hm[n, k])
+            index = int(c[0] + c[1] * W + W * H * (n * K + k))
+            c = c + np.array([ox[index], oy[index]], dtype=np.float32)
             preds[n, k] = to_image(c, center[n], scale[n], W, H, True) if image_space else c
             maxvals[n, k] = v
     return preds, maxvals

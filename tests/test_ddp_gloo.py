@@ -64,6 +64,28 @@ def _worker(rank, world, port, depth, bpb, q):
         v = reduce_scalars(torch.tensor([float(rank), 2.0]))
         assert torch.allclose(v, torch.tensor([(world - 1) / 2.0, 2.0]))
         assert shard_batch(8 * world, rank, world) == (8 * rank, 8 * rank + 8)
+        # the logged scalars of one iteration (detectors/base.py:38-76): averaged over ranks in ONE collective
+        from vitpose_amd.models import TopDown
+        calls, real = [], dist.all_reduce
+
+        def counted(t, *a, **k):
+            calls.append(t.numel())
+            return real(t, *a, **k)
+        dist.all_reduce = counted
+        try:
+            loss, log_vars = TopDown._parse_losses(dict(heatmap_loss=torch.tensor(1.0 + rank, requires_grad=True),
+                                                        aux_loss=[torch.tensor([2.0, 4.0]), torch.tensor(float(rank))],
+                                                        acc_pose=0.25 + rank))
+        finally:
+            dist.all_reduce = real
+        assert calls == [3], calls                               # heatmap_loss, aux_loss, loss: one vector, one call
+        assert loss.requires_grad and abs(float(loss) - (1.0 + rank + 3.0 + rank)) < 1e-6     # the local loss, untouched
+        mean_rank = (world - 1) / 2.0
+        assert log_vars['acc_pose'] == 0.25 + rank              # a float is logged as it is (base.py:47-48)
+        assert abs(log_vars['heatmap_loss'] - (1.0 + mean_rank)) < 1e-6
+        assert abs(log_vars['aux_loss'] - (3.0 + mean_rank)) < 1e-6
+        assert abs(log_vars['loss'] - (4.0 + 2 * mean_rank)) < 1e-6
+        assert list(log_vars) == ['heatmap_loss', 'aux_loss', 'acc_pose', 'loss']
         q.put((rank, 'ok'))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))
@@ -83,3 +105,98 @@ def test_gradient_buckets_two_gloo_ranks(depth, bpb):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_parse_losses_without_process_group():
+    """detectors/base.py:38-76 on one process: tensors are averaged, lists of tensors summed, every key containing
+    'loss' enters the total, a float is logged unchanged, anything else is a TypeError."""
+    from vitpose_amd.models import TopDown
+    loss, log_vars = TopDown._parse_losses(dict(heatmap_loss=torch.tensor([1.0, 3.0]), acc_pose=0.5,
+                                                other_loss=[torch.tensor(1.0), torch.tensor([2.0, 4.0])]))
+    assert float(loss) == 6.0 and log_vars == dict(heatmap_loss=2.0, acc_pose=0.5, other_loss=4.0, loss=6.0)
+    with pytest.raises(TypeError):
+        TopDown._parse_losses(dict(heatmap_loss='nan'))
+
+
+def test_rccl_branch_is_stream_ordered(monkeypatch):
+    """The overlapped (RCCL) branch of GradBuckets with the device API replaced by recorders: every collective is
+    enqueued under the communication stream, behind a wait for an event recorded on the compute stream at the
+    bucket's trigger point; the compute stream waits exactly once, for an event recorded behind the LAST
+    collective; the bf16 buckets are widened back only after that wait; nothing blocks the host."""
+    from vitpose_amd import ddp
+    log = []
+
+    class Stream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_event(self, ev):
+            log.append(('wait', self.name, ev.id))
+
+        def synchronize(self):
+            log.append(('host_sync', self.name))
+
+    class Event:
+        n = 0
+
+        def __init__(self, enable_timing=False):
+            Event.n += 1
+            self.id = Event.n
+
+        def record(self, stream):
+            log.append(('record', stream.name, self.id))
+
+        def synchronize(self):
+            log.append(('host_sync', 'event'))
+
+    compute, comm_stream = Stream('compute'), Stream('comm')
+    current = [compute]
+
+    class StreamCtx:
+        def __init__(self, st):
+            self.st = st
+
+        def __enter__(self):
+            self.prev, current[0] = current[0], self.st
+
+        def __exit__(self, *exc):
+            current[0] = self.prev
+
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: current[0])
+    monkeypatch.setattr(torch.cuda, 'Event', Event)
+    monkeypatch.setattr(torch.cuda, 'stream', StreamCtx)
+    monkeypatch.setattr(ddp.dist, 'all_reduce',
+                        lambda t, op=None, group=None: log.append(('all_reduce', current[0].name, t.numel(), t.dtype)))
+
+    class Store:
+        grad = torch.zeros(1000)
+        numel = 1000
+
+    for bf16 in (False, True):
+        log.clear()
+        gb = object.__new__(ddp.GradBuckets)
+        gb.store, gb.group, gb.world, gb.on_gpu, gb.stream, gb.overlap = Store, None, 2, True, comm_stream, True
+        gb.pending, gb.launched, gb.measure, gb.timings, gb._t_first = [], 0, False, [], None
+        gb.bf16, gb.stage, gb.staged = bf16, torch.zeros(1000, dtype=torch.bfloat16), []
+        gb._cast = lambda src, dst, lo, hi: log.append(('cast', current[0].name, str(src.dtype), lo, hi))
+        gb.triggers, gb.tail = {2: (600, 1000), 1: (300, 600)}, (0, 300)
+        plan = _HostPlan()
+        gb.after_block(plan, 2)
+        gb.after_block(plan, 1)
+        gb.finish(plan)
+        plan.run()
+        assert not [e for e in log if e[0] == 'host_sync']
+        ars = [i for i, e in enumerate(log) if e[0] == 'all_reduce']
+        assert len(ars) == 3 and all(log[i][1] == 'comm' for i in ars)
+        assert [log[i][2] for i in ars] == [400, 300, 300]
+        assert all(log[i][3] == (torch.bfloat16 if bf16 else torch.float32) for i in ars)
+        for i in ars:            # hand-over: record on compute, comm waits for that event, then the collective
+            assert log[i - 2][:2] == ('record', 'compute') and log[i - 1] == ('wait', 'comm', log[i - 2][2])
+            if bf16:             # narrowed on the compute stream BEFORE the hand-over event
+                assert log[i - 3][:3] == ('cast', 'compute', 'torch.float32')
+        tail = log[ars[-1] + 1:]
+        assert tail[0][:2] == ('record', 'comm') and tail[1] == ('wait', 'compute', tail[0][2])
+        assert len([e for e in log if e[0] == 'wait' and e[1] == 'compute']) == 1
+        widen = [e for e in tail[2:] if e[0] == 'cast']
+        assert len(widen) == (3 if bf16 else 0) and all(e[1] == 'compute' and e[2] == 'torch.bfloat16' for e in widen)
+        assert gb.launched == 0 and not gb.staged

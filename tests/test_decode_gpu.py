@@ -111,6 +111,17 @@ def test_blurred_branches_on_device_vs_oracle(dev, gold):
         assert p.shape == (N, 6, 2) and m.shape == (N, 6, 1)
         np.testing.assert_allclose(p, po, atol=5e-3, err_msg=f'CombinedTarget kernel {ks}')
         np.testing.assert_allclose(m, mo, atol=1e-6)
+    # joints without a positive maximum: the reference's arg-max is (-1, -1) and its flattened offset lookup
+    # (top_down_eval.py:582-585) then reads the previous joint's maps -- the first joint of the batch wraps to the last
+    dead = ct.copy()
+    dead[0, 0] = -np.abs(dead[0, 0])             # first joint of the batch (the wrap-around case)
+    dead[1, 3 * 2] = 0.0                         # an all-zero map in the middle
+    dead[N - 1, 3 * 5] = -1.0                    # the last joint
+    p, m = f(torch.from_numpy(dead).to(dev), c, s, use_udp=True, target_type='CombinedTarget', kernel=11)
+    po, mo = D.combined_target_decode(dead, c, s, kernel=11)
+    assert mo[0, 0, 0] <= 0 and mo[1, 2, 0] <= 0 and mo[N - 1, 5, 0] <= 0
+    np.testing.assert_allclose(p, po, atol=5e-3, err_msg='CombinedTarget, joints without a positive maximum')
+    np.testing.assert_allclose(m, mo, atol=1e-6)
 
 
 def test_head_decode_every_test_cfg_on_device(dev, gold):

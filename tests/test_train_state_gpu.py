@@ -139,6 +139,7 @@ def test_optimizer_state_checkpoint_round_trip(dev, tmp_path):
     for _ in range(3):
         step(m, opt)
     f = str(tmp_path / 'ck.pth')
+    m._engine.vit._dp_counter = 7                    # (rate 0 here: the DropPath stream has not moved by itself)
     save_checkpoint(m, f, optimizer=opt, meta=dict(iter=3))
     with pytest.raises(TypeError):
         save_checkpoint(m, str(tmp_path / 'bad.pth'), optimizer=object())
@@ -154,6 +155,7 @@ def test_optimizer_state_checkpoint_round_trip(dev, tmp_path):
         if with_state:
             o2.load_state_dict(ck['optimizer'])
             assert m2._engine.optimizer.step_count == 3
+            assert m2._engine.vit._dp_counter == 7   # the DropPath stream resumes where the checkpoint left it
         step(m2, o2)
         return m2
     step(m, opt)                                    # the run that never stopped
@@ -224,3 +226,46 @@ def test_drop_path_kernel_statistics(dev):
     vr.sample_drop_path(dp, active=[True, False, True, False])
     assert float((dp[1] - 1).abs().max()) == 0.0 and float((dp[3] - 1).abs().max()) == 0.0
     assert (dp[2] == 0).any()
+
+
+def test_inputs_read_in_place_survive_address_reuse(dev):
+    """The training plan reads contiguous f32 inputs in place by patching its recorded pointer arguments.  A later
+    batch may put the images at the address an earlier batch's targets had (the caching allocator reuses freed
+    blocks): every input must still reach its own kernels.  Two batches laid out in one arena with the image and the
+    target addresses exchanged between them, against the same batches through the copy path."""
+    m, _ = build(dev)
+    m.train()
+    eng = m._engine
+    B = 2
+    n_img, n_tgt = B * 3 * 256 * 192, B * 17 * 64 * 48
+    arena = torch.empty(2 * n_img, device=dev)            # two image-sized halves; a target fits in either
+    (img1, tgt1, tw1), (img2, tgt2, tw2) = O.synth_batch(B, seed=3), O.synth_batch(B, seed=4)
+
+    def in_place(img, tgt, img_half):
+        a = arena[img_half * n_img:(img_half + 1) * n_img].view(B, 3, 256, 192)
+        t = arena[(1 - img_half) * n_img:(1 - img_half) * n_img + n_tgt].view(B, 17, 64, 48)
+        a.copy_(img), t.copy_(tgt)
+        return a, t
+
+    def copied(img, tgt, tw):
+        # non-contiguous views: the engine has to copy them into its own buffers
+        wide_i = torch.zeros(B, 3, 256, 193, device=dev)
+        wide_t = torch.zeros(B, 17, 64, 49, device=dev)
+        wide_i[..., :192] = img.to(dev)
+        wide_t[..., :48] = tgt.to(dev)
+        loss, _ = eng.forward_backward(wide_i[..., :192], wide_t[..., :48], tw.to(dev), drop_path=False)
+        return float(loss), eng.store.grad.clone()
+
+    want1, want2 = copied(img1, tgt1, tw1), copied(img2, tgt2, tw2)
+    assert abs(want1[0] - want2[0]) > 1e-4 * abs(want1[0])          # the two batches are told apart by their loss
+    for rounds in range(2):                                         # exchange the addresses twice
+        for (img, tgt, tw), half, want in (((img1, tgt1, tw1), 0, want1), ((img2, tgt2, tw2), 1, want2)):
+            a, t = in_place(img, tgt, half)
+            w = tw.to(dev).contiguous()
+            loss, _ = eng.forward_backward(a, t, w, drop_path=False)
+            torch.cuda.synchronize()
+            assert abs(float(loss) - want[0]) <= 1e-5 * abs(want[0]), (rounds, half, float(loss), want[0])
+            assert ((eng.store.grad - want[1]).norm() / want[1].norm()).item() < 2e-2
+    # back through the copy path after in-place batches: the plan's own buffers are bound again
+    again = copied(img1, tgt1, tw1)
+    assert abs(again[0] - want1[0]) <= 1e-5 * abs(want1[0])

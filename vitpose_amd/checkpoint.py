@@ -51,16 +51,18 @@ def adapt_backbone_state_dict(model, state_dict, patch_padding='pad'):
 
 
 def split_expert_state_dict(model, state_dict, part_features):
-    """mmcv_custom/checkpoint.py:396-404: a plain-ViT state dict enters a ViTMoE model by cutting every fc2
-    tensor into its first rows (the shared fc2) and its last `part_features` rows (copied into every expert)."""
-    import re
-    new = OrderedDict(state_dict)
-    for key in model.state_dict().keys():
-        if 'mlp.experts' in key:
-            new[key] = state_dict[re.sub(r'experts.\d+.', 'fc2.', key)][-part_features:]
-        elif 'fc2' in key:
-            new[key] = state_dict[key][:-part_features]
-    return new
+    """mmcv_custom/checkpoint.py:396-404: a plain-ViT state dict enters a ViTMoE model.  Every fc2 tensor of the file
+    has E rows; the model's shared fc2 takes the first E - part_features of them and each of its experts a copy of
+    the last part_features."""
+    out = OrderedDict(state_dict)
+    for key in model.state_dict():
+        block, is_expert, rest = key.partition('.mlp.experts.')
+        if is_expert:
+            leaf = rest.split('.', 1)[1]                      # 'weight' / 'bias' behind the expert's number
+            out[key] = state_dict[f'{block}.mlp.fc2.{leaf}'][-part_features:]
+        elif '.mlp.fc2.' in key:
+            out[key] = state_dict[key][:-part_features]
+    return out
 
 
 def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None, patch_padding='pad',

@@ -181,11 +181,17 @@ __global__ __launch_bounds__(256) void decode_blur_kernel(const float* __restric
     float outx, outy, score;
     if (mode == 5) {
         const bool valid = bbest > 0.f;
-        const int px = valid ? bidx % W : 0, py = valid ? bidx / W : 0;   // an invalid joint reads the corner offsets
+        // A joint without a positive maximum has the arg-max (-1, -1) (_get_max_preds), and the reference still looks
+        // its offsets up, at flat index -1 - W + W * H * j of the flattened offset maps (top_down_eval.py:582-585):
+        // that is pixel (H - 2, W - 1) of the PREVIOUS joint's offset maps, and for the very first joint numpy's
+        // negative index wraps to the last joint of the batch.  Same lookup here.
+        const int px = valid ? bidx % W : W - 1, py = valid ? bidx / W : H - 2;
+        const int owner = valid ? (int)blockIdx.x : (blockIdx.x == 0 ? (int)gridDim.x - 1 : (int)blockIdx.x - 1);
+        const float* osrc = heat + (size_t)owner * 3 * HW;
         const int m = bk.n, r = m >> 1;
         if (tid < 2 * m) {
             const int which = tid / m, i = tid - which * m;
-            const float* row = src + (size_t)(1 + which) * HW + reflect101(py + i - r, H) * W;
+            const float* row = osrc + (size_t)(1 + which) * HW + reflect101(py + i - r, H) * W;
             float acc = 0.f;
             for (int j = 0; j < m; ++j) acc += bk.k[j] * row[reflect101(px + j - r, W)];
             rowdot[which * VP_DECODE_MAX_KERNEL + i] = acc;

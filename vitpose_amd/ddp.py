@@ -27,6 +27,10 @@ class GradBuckets:
         self.stream = torch.cuda.Stream(device=store.device) if self.on_gpu else None
         # asynchronous, stream-ordered collectives (overlapped with the rest of backward) exist with RCCL only
         self.overlap = self.on_gpu and dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
+        if self.overlap and os.environ.get('TORCH_NCCL_BLOCKING_WAIT', '0') == '1':
+            import warnings
+            warnings.warn('TORCH_NCCL_BLOCKING_WAIT=1 makes every all_reduce block the host until it has completed: the '
+                          'gradient exchange is then serialised with the backward pass instead of overlapping it')
         self.pending = []          # (kept for callers that look at it: always empty, no Work handles are held)
         self.launched = 0          # collectives enqueued on the communication stream since the last wait()
         self.measure = False       # True: wait() brackets itself with timing events (bench.py --gpus N)

@@ -1274,12 +1274,18 @@ class TopDown(nn.Module):
                 raise TypeError(f'{name} is not a tensor or list of tensors or float')
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         log_vars['loss'] = loss
-        for name, value in log_vars.items():
-            if not isinstance(value, float):
-                if dist.is_available() and dist.is_initialized():
-                    value = value.data.clone()
-                    dist.all_reduce(value.div_(dist.get_world_size()))
-                log_vars[name] = value.item()
+        # The reference all-reduces and reads back (.item()) every logged scalar by itself (base.py:66-72): two
+        # collectives and two host syncs per iteration for ViTPose.  Here all tensor-valued entries travel as ONE small
+        # vector: one collective (only when a process group exists), one copy to the host.
+        names = [k for k, v in log_vars.items() if not isinstance(v, float)]
+        if names:
+            from .ddp import reduce_scalars
+            dev = loss.device if isinstance(loss, torch.Tensor) else log_vars[names[0]].device
+            vals = torch.stack([log_vars[k].detach().to(dev, torch.float32).reshape(()) for k in names])
+            if dist.is_available() and dist.is_initialized():
+                vals = reduce_scalars(vals)
+            for k, v in zip(names, vals.tolist()):
+                log_vars[k] = v
         return loss, log_vars
 
     def train_step(self, data_batch, optimizer, **kwargs):
@@ -1416,7 +1422,13 @@ class _FlatOptimizer:
         self.model._engine.optimizer_step(lr)
 
     def state_dict(self):
-        return self.model._engine.optimizer.state_dict()
+        """The fused AdamW's state + the position of the DropPath random stream (the sampling kernel is keyed by
+        torch.initial_seed() and a per-model step counter: a resumed run must not replay the masks of its first steps)."""
+        sd = self.model._engine.optimizer.state_dict()
+        sd['drop_path_counter'] = int(self.model._engine.vit._dp_counter)
+        return sd
 
     def load_state_dict(self, sd):
         self.model._engine.optimizer.load_state_dict(sd)
+        if 'drop_path_counter' in sd:
+            self.model._engine.vit._dp_counter = int(sd['drop_path_counter'])

@@ -18,28 +18,22 @@ from . import _lib
 
 
 def get_warp_matrix(theta, size_input, size_dst, size_target):
-    """core/post_processing/post_transforms.py:291-320 (UDP)."""
-    theta = np.deg2rad(theta)
-    matrix = np.zeros((2, 3), dtype=np.float32)
-    scale_x = size_dst[0] / size_target[0]
-    scale_y = size_dst[1] / size_target[1]
-    matrix[0, 0] = math.cos(theta) * scale_x
-    matrix[0, 1] = -math.sin(theta) * scale_x
-    matrix[0, 2] = scale_x * (-0.5 * size_input[0] * math.cos(theta) + 0.5 * size_input[1] * math.sin(theta)
-                              + 0.5 * size_target[0])
-    matrix[1, 0] = math.sin(theta) * scale_y
-    matrix[1, 1] = math.cos(theta) * scale_y
-    matrix[1, 2] = scale_y * (-0.5 * size_input[0] * math.sin(theta) - 0.5 * size_input[1] * math.cos(theta)
-                              + 0.5 * size_target[1])
-    return matrix
+    """The unbiased-data-processing warp (core/post_processing/post_transforms.py:291-320) as one product: a point p
+    of the source goes to  diag(s) (R(theta) (p - size_input / 2) + size_target / 2)  with s = size_dst / size_target,
+    i.e. the 2 x 3 matrix  diag(s) [R | (size_target - R size_input) / 2]  (f32, like the reference's)."""
+    a = math.radians(theta)
+    rot = np.array([[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]])
+    size_input, size_target = np.asarray(size_input, dtype=np.float64), np.asarray(size_target, dtype=np.float64)
+    s = np.asarray(size_dst, dtype=np.float64) / size_target
+    shift = 0.5 * (size_target - rot @ size_input)
+    return (s[:, None] * np.column_stack((rot, shift))).astype(np.float32)
 
 
 def warp_affine_joints(joints, mat):
-    """post_transforms.py:323-342."""
-    joints = np.array(joints)
-    shape = joints.shape
-    joints = joints.reshape(-1, 2)
-    return np.dot(np.concatenate((joints, joints[:, 0:1] * 0 + 1), axis=1), mat.T).reshape(shape)
+    """post_transforms.py:323-342: every (x, y) pair of `joints` (any leading shape) through the 2 x 3 matrix."""
+    joints = np.asarray(joints)
+    mat = np.asarray(mat)
+    return joints @ mat[:, :2].T + mat[:, 2]
 
 
 def get_affine_transform(center, scale, rot, output_size):

@@ -594,17 +594,20 @@ class Plan:
             sizes = (ctypes.c_int * len(grp))(*[t.numel() for t in grp])
             self._add('vp_zero_regions', ptrs, sizes, len(grp), keep=(ptrs, sizes) + tuple(grp))
 
-    def rebind(self, old_ptr, new_ptr):
-        """Point every recorded pointer argument that equals `old_ptr` at `new_ptr` (an input buffer of the plan
-        replaced by the caller's own tensor of the same shape: saves the copy).  Returns the number of arguments
-        changed; the caller keeps the new tensor alive until the plan has run."""
-        n = 0
-        for _, _, args in self.calls:
-            for a in args:
-                if isinstance(a, c_void_p) and a.value == old_ptr:
-                    a.value = new_ptr
-                    n += 1
-        return n
+    def slots_of(self, t):
+        """The recorded pointer arguments that hold the address of tensor `t` -- the argument OBJECTS, to be taken
+        right after recording, while every buffer of the plan still has an address of its own.  `rebind` then moves
+        exactly these, whatever addresses later inputs happen to land on."""
+        ptr = t.data_ptr()
+        return [a for _, _, args in self.calls for a in args if isinstance(a, c_void_p) and a.value == ptr]
+
+    @staticmethod
+    def rebind(slots, new_ptr):
+        """Point the argument slots of one input (from `slots_of`) at `new_ptr`: the caller's own tensor of the
+        recorded shape is then read in place (saves the copy).  The caller keeps that tensor alive until the plan
+        has run."""
+        for a in slots:
+            a.value = new_ptr
 
     def scale_bf16(self, x, scale):
         """x (bf16) *= scale[0] (a device scalar)."""

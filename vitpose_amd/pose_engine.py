@@ -221,21 +221,22 @@ class PoseEngine:
         images whose dataset index is j, every other image's target weights (and targets) are zeroed."""
         B = img.shape[0]
         plan = self.plans[('train', B)][0]
-        bound = io.setdefault('_bound', {})
+        # argument slots of the three inputs, taken while each still holds its own plan buffer's address: a caller's
+        # tensor may later sit at an address another input was bound to before (the caching allocator reuses freed
+        # blocks), so inputs are never matched by address again
+        slots = io.get('_slots')
+        if slots is None:
+            slots = io['_slots'] = {k: plan.slots_of(io[k]) for k in ('img', 'target', 'tw')}
+            if not all(slots.values()):
+                raise RuntimeError('an input of the training plan has no recorded argument slot')
         for k, t in (('img', img), ('target', target), ('tw', target_weight.reshape(B, self.K))):
-            cur = bound.get(k, io[k].data_ptr())
-            if t.data_ptr() == cur:
-                continue
             if (not self.multi and t.dtype == torch.float32 and t.is_contiguous() and t.device == io[k].device
                     and t.shape == io[k].shape and t.data_ptr() % 16 == 0):
                 # the caller's tensor has the plan's layout: the forward kernels read it in place (they are the only
                 # readers; stream order keeps the memory valid until they have run)
-                plan.rebind(cur, t.data_ptr())
-                bound[k] = t.data_ptr()
+                plan.rebind(slots[k], t.data_ptr())
             else:
-                if cur != io[k].data_ptr():
-                    plan.rebind(cur, io[k].data_ptr())
-                    bound.pop(k, None)
+                plan.rebind(slots[k], io[k].data_ptr())
                 io[k].copy_(t)
         if not self.multi:
             return
