@@ -37,7 +37,7 @@ def test_product_host_matrices_match_reference_and_oracle(gold):
     from vitpose_amd import pipelines as V
     for b, r in enumerate(P.synth_samples(6, K=K, seed=80)):
         trans = V.get_warp_matrix(r['rotation'], r['center'] * 2.0, IMG - 1.0, r['scale'] * 200.0)
-        np.testing.assert_allclose(trans, gold[f'trans_{b}'], rtol=1e-6, atol=1e-5)
+        assert trans.dtype == np.float32 and np.array_equal(trans, gold[f'trans_{b}'])   # bit for bit: the image warp is integer work
         np.testing.assert_allclose(V.warp_affine_joints(r['joints_3d'][:, :2], gold[f'trans_{b}']),
                                    gold[f'joints_{b}'][:, :2], rtol=1e-5, atol=1e-3)
         a = V.get_affine_transform(r['center'], r['scale'], r['rotation'], IMG)

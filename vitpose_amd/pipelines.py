@@ -18,15 +18,22 @@ from . import _lib
 
 
 def get_warp_matrix(theta, size_input, size_dst, size_target):
-    """The unbiased-data-processing warp (core/post_processing/post_transforms.py:291-320) as one product: a point p
-    of the source goes to  diag(s) (R(theta) (p - size_input / 2) + size_target / 2)  with s = size_dst / size_target,
-    i.e. the 2 x 3 matrix  diag(s) [R | (size_target - R size_input) / 2]  (f32, like the reference's)."""
-    a = math.radians(theta)
-    rot = np.array([[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]])
-    size_input, size_target = np.asarray(size_input, dtype=np.float64), np.asarray(size_target, dtype=np.float64)
-    s = np.asarray(size_dst, dtype=np.float64) / size_target
-    shift = 0.5 * (size_target - rot @ size_input)
-    return (s[:, None] * np.column_stack((rot, shift))).astype(np.float32)
+    """The unbiased-data-processing warp (core/post_processing/post_transforms.py:291-320): a source point p goes to
+    diag(s) (R(theta) (p - size_input / 2) + size_target / 2) with s = size_dst / size_target, i.e. the 2 x 3 matrix
+    diag(s) [R | size_target / 2 - R size_input / 2].  The terms are summed in the order and in the precision the
+    reference's scalar expressions have (the arguments' own dtype -- f32 in the pipeline -- with cos / sin rounded to
+    it), so the matrix, and with it the integer warp of the image, is the reference's bit for bit."""
+    theta = np.deg2rad(theta)
+    c, s = math.cos(theta), math.sin(theta)
+    size_input, size_dst, size_target = np.asarray(size_input), np.asarray(size_dst), np.asarray(size_target)
+    half_in, half_target = 0.5 * size_input, 0.5 * size_target
+    scale = size_dst / size_target
+    shift = ((-half_in[0]) * np.array([c, s], dtype=half_in.dtype) + half_in[1] * np.array([s, -c], dtype=half_in.dtype)
+             + half_target)
+    matrix = np.empty((2, 3), dtype=np.float32)
+    matrix[:, :2] = np.array([[c, -s], [s, c]], dtype=scale.dtype) * scale[:, None]
+    matrix[:, 2] = scale * shift
+    return matrix
 
 
 def warp_affine_joints(joints, mat):
