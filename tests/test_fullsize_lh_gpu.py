@@ -130,7 +130,7 @@ def test_full_depth_forward_backward_vs_oracle(dev, name, seed):
     assert ref.abs().max() > 0.5
     r_heat = rel(heat, ref.detach())
     print(f'ViTPose-{name} x {B}, {depth} Blocks: loss {loss.item():.6f} vs {rl.item():.6f}, heat rel {r_heat:.2e}')
-    assert meas(f'{name} full-depth heat rel', r_heat) < 1.5e-2
+    assert meas(f'{name} full-depth heat rel', r_heat) < 1.35e-2
     assert abs(loss.item() - rl.item()) < 2e-2 * rl.item()
     mid = depth // 2
     names = [f'blocks.{i}.{p}' for i in (0, mid, depth - 1)
@@ -147,9 +147,10 @@ def test_full_depth_forward_backward_vs_oracle(dev, name, seed):
     worst = max(e2e.items(), key=lambda kv: kv[1])
     print(f'  end to end: worst backbone gradient {worst[0]} {worst[1]:.2e}; head ' +
           ', '.join(f'{k} {v:.2e}' for k, v in head.items()))
-    # measured + 50 % (batch 2: the ReLU-mask flips of the head are not averaged out as they are at batch 32 / 64)
-    assert meas(f'{name} full-depth e2e worst backbone grad', worst[1]) < 0.15, worst
-    assert meas(f'{name} full-depth worst head grad', max(head.values())) < 0.12, head
+    # measured (L / H): worst backbone tensor 4.0e-2 / 3.8e-2 (the patch embedding, at the far end of 24 / 32 Blocks),
+    # worst head tensor 2.0e-2 / 1.8e-2; bounds = measured + 50 %
+    assert meas(f'{name} full-depth e2e worst backbone grad', worst[1]) < 6e-2, worst
+    assert meas(f'{name} full-depth worst head grad', max(head.values())) < 3e-2, head
     # the backbone alone, from the oracle's own feature-map gradient
     plan, _ = eng._train_plan(B)
     idx = next(i for i in range(eng.n_fwd_calls, len(plan)) if plan.calls[i][0] == 'vp_layernorm_bwd')
@@ -162,4 +163,5 @@ def test_full_depth_forward_backward_vs_oracle(dev, name, seed):
     worst = max(alone.items(), key=lambda kv: kv[1])
     print(f'  backbone backward alone ({depth} Blocks): worst {worst[0]} {worst[1]:.2e}; first Block qkv.weight '
           f"{alone['blocks.0.attn.qkv.weight']:.2e}, patch_embed {alone['patch_embed.proj.weight']:.2e}")
-    assert meas(f'{name} full-depth backbone-alone worst grad', worst[1]) < 3e-2, worst
+    # measured 7.7e-3 (L) / 8.2e-3 (H), both on the patch embedding; first Block's qkv weight 5.3e-3 / 6.2e-3
+    assert meas(f'{name} full-depth backbone-alone worst grad', worst[1]) < 1.25e-2, worst

@@ -37,13 +37,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         g[i] = ok ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
         b[i] = ok ? *reinterpret_cast<const f32x4*>(beta + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // two rows per iteration: twice the bytes in flight per wave
-    for (int row0 = blockIdx.x * 4 + (threadIdx.x >> 6); row0 < M; row0 += 2 * nwaves) {
+    // A wave walks the row pairs (w, w + W), (w + 2 W, w + 3 W), ... (W = waves of the grid) through TWO register
+    // buffers: while pair p is reduced, normalised and stored, the loads of pair p + 1 are in flight, and pair p + 2 is
+    // requested as soon as p's registers are free -- reads and writes of a wave overlap, and so do those of the waves
+    // of a CU, instead of every wave of the chip loading, then every wave storing.
+    auto load_pair = [&](int row0, f32x4 (&v0)[CH], f32x4 (&v1)[CH]) {
         const int row1 = row0 + nwaves;
-        const bool has1 = row1 < M;
         const float* xr0 = x + (size_t)row0 * E;
-        const float* xr1 = x + (size_t)(has1 ? row1 : row0) * E;
-        f32x4 v0[CH], v1[CH];
+        const float* xr1 = x + (size_t)(row1 < M ? row1 : row0) * E;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c = lane + 64 * i;
@@ -51,6 +52,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             v0[i] = ok ? *reinterpret_cast<const f32x4*>(xr0 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
             v1[i] = ok ? *reinterpret_cast<const f32x4*>(xr1 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto process_pair = [&](int row0, f32x4 (&v0)[CH], f32x4 (&v1)[CH]) {
+        const int row1 = row0 + nwaves;
+        const bool has1 = row1 < M;
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -121,6 +126,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 }
             }
         }
+    };
+    f32x4 a0[CH], a1[CH], b0[CH], b1[CH];
+    int rowA = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rowA >= M) return;
+    int rowB = rowA + 2 * nwaves;
+    load_pair(rowA, a0, a1);
+    if (rowB < M) load_pair(rowB, b0, b1);
+    while (true) {
+        process_pair(rowA, a0, a1);
+        rowA += 4 * nwaves;
+        if (rowA < M) load_pair(rowA, a0, a1);
+        if (rowB >= M) break;
+        process_pair(rowB, b0, b1);
+        rowB += 4 * nwaves;
+        if (rowB < M) load_pair(rowB, b0, b1);
+        if (rowA >= M) break;
     }
 }
 
@@ -322,6 +343,16 @@ extern "C" int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats) {
     return ln_bwd_blocks(M, E, workspace_floats);
 }
 
+// workgroups of the forward kernel (tuning hook: VP_LN_FWD_BLOCKS)
+static int ln_fwd_block_cap() {
+    static const int cap = [] {
+        const char* e = getenv("VP_LN_FWD_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 768;
+    }();
+    return cap;
+}
+
 extern "C" int vp_layernorm_bwd_finalize(const vp_ln_partial* table_dev, int count, int E, hipStream_t stream) {
     VP_CHECK_ARG(table_dev && count > 0 && count <= 65535 && E > 0);
     hipLaunchKernelGGL(ln_bwd_finalize_batched_kernel, dim3((3 * E + 15) / 16, count), dim3(256), 0, stream, table_dev, E);
@@ -333,7 +364,8 @@ extern "C" int vp_layernorm_fwd(const float* x, const float* gamma, const float*
     VP_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32));
     VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * 8);
     int blocks = (M + 7) / 8;              // 4 waves x 2 rows per pass
-    if (blocks > 1536) blocks = 1536;      // persistent: ~24 waves per CU, each walking a few rows
+    const int cap = ln_fwd_block_cap();
+    if (blocks > cap) blocks = cap;
 #define VP_LNF(CH)                                                                                                  \
     hipLaunchKernelGGL((ln_fwd_kernel<CH, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, \
                        y_f32, mean, rstd, M, E, eps, 0)
@@ -356,7 +388,8 @@ extern "C" int vp_layernorm_fwd_pair(const float* x, const float* gamma, const f
     VP_CHECK_ARG(x && gamma && beta && y_pair);
     VP_CHECK_ARG(M > 0 && E > 0 && E % 32 == 0 && E <= 256 * 8);
     int blocks = (M + 7) / 8;
-    if (blocks > 1536) blocks = 1536;
+    const int cap = ln_fwd_block_cap();
+    if (blocks > cap) blocks = cap;
 #define VP_LNP(CH)                                                                                                   \
     hipLaunchKernelGGL((ln_fwd_kernel<CH, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_pair, \
                        y_f32, (float*)nullptr, (float*)nullptr, M, E, eps, relu)

@@ -116,7 +116,12 @@ class Workspace:
 
 SPLITK_TARGET_BLOCKS = 512  # ~2 workgroups per CU
 # Blocks whose weight gradients share one grouped launch (0: one split-K launch per weight instead)
-WGRAD_GROUP_BLOCKS = int(os.environ.get('VITPOSE_WGRAD_GROUP', '4'))
+# Blocks per grouped weight-gradient launch.  VITPOSE_WGRAD_GROUP pins it; unset, a pass with gradient buckets (N > 1)
+# uses 4 -- the launches are the hand-over points of the buckets, and 4 Blocks of ViTPose-B are exactly three rounds of
+# the chip -- and a pass without any (one GPU) defers EVERY Block's weight gradients to one launch at the end of the
+# backward pass: 2304 tiles = nine rounds with one tail instead of three (0.500 against 0.489 of the MFMA peak).
+_WGRAD_GROUP_ENV = os.environ.get('VITPOSE_WGRAD_GROUP')
+WGRAD_GROUP_BLOCKS = int(_WGRAD_GROUP_ENV) if _WGRAD_GROUP_ENV else 4
 
 
 def _split_k(M, N, K, target_blocks=None):
@@ -449,6 +454,8 @@ class VitRunner:
         # launch per `group_blocks` Blocks: 4 Blocks of ViTPose-B are 768 tiles of 192 x 192 = 3 whole
         # rounds of the chip, no slices, no slabs.
         G = group_blocks if group_blocks is not None else WGRAD_GROUP_BLOCKS
+        if group_blocks is None and not _WGRAD_GROUP_ENV and after_block is None and not self.part:
+            G = self.depth
         P, Ns = self.part, self.E - self.part
         if P:
             G = max(G, 1)     # the expert weight gradients exist in the grouped launch only
