@@ -156,11 +156,12 @@ def cpu_baseline(model_key, batch, mode, iters=None):
                        f'the CPU share of this job ({visible} logical CPUs visible on the machine)')
 
 
-def pmc_traffic(kernel_key, flop_per_launch):
+def pmc_traffic(workload, kernel_key, flop_per_launch):
     """(HBM bytes per launch, where the figure comes from) for the dominant kernel.  The bytes are counters of an
     earlier profiling run of this command (rocprofv3 --pmc passes cannot run inside the bench), committed as
-    profiles/pmc_traffic.json by tools/pmc_traffic.py together with the tree state and launch size they were taken
-    on; a record taken on a launch of a different size does not describe this run and gives (None, reason)."""
+    profiles/pmc_traffic.json by tools/pmc_traffic.py under "<mode>_<model><batch>:<kernel>" together with the tree
+    state and the launch size they were taken on; a record of another workload or of launches of another size does
+    not describe this run and gives (None, reason)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if not os.path.exists(path):
         return None, 'profiles/pmc_traffic.json not found'
@@ -168,10 +169,10 @@ def pmc_traffic(kernel_key, flop_per_launch):
         d = json.load(open(path))
     except (OSError, ValueError) as e:
         return None, f'profiles/pmc_traffic.json unreadable: {e}'
-    rec = d.get(kernel_key)
+    rec = d.get(f'{workload}:{kernel_key}')
     if not rec:
-        return None, f'profiles/pmc_traffic.json has no record for {kernel_key}'
-    src = f"profiles/pmc_traffic.json (state {d.get('_state', '?')}, {d.get('_source', 'rocprofv3 --pmc TCC_EA0_RDREQ / WRREQ passes')})"
+        return None, f'profiles/pmc_traffic.json has no record for {workload}:{kernel_key}'
+    src = f"profiles/pmc_traffic.json (state {d.get('_state', '?')}; {d.get('_source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})"
     want = rec.get('gflop_per_launch')
     if want is not None and abs(want - flop_per_launch / 1e9) > 0.01 * want:
         return None, src + f": taken on launches of {want} GFLOP, this run's are {flop_per_launch / 1e9:.1f}"
@@ -206,6 +207,8 @@ def main():
     ap.add_argument('--plus', action='store_true',
                     help='ViTPose+ (ViTMoE backbone, TopDownMoE detector with 6 heads) instead of the headline model')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--no-default-iter', action='store_true',
+                    help='skip the second figure (the reference-default iteration through model.train_step): profiling runs')
     ap.add_argument('--exact', action='store_true',
                     help='--mode infer only: the fp32-accurate evaluation path (test_cfg fp32_exact: split3 GEMMs on '
                          'hi/lo bf16 pairs, everything else f32) instead of the bf16 path')
@@ -383,7 +386,7 @@ def main():
     # accuracy of every iteration (topdown_heatmap_simple_head.py:170-195) and the logged scalars reduced over ranks
     # and read on the host (_parse_losses, base.py:38-76) -- what a user gets without `train_cfg.skip_accuracy`.
     default_iter = None
-    if args.mode == 'train' and not args.plus:
+    if args.mode == 'train' and not args.plus and not args.no_default_iter:
         model.train_cfg['skip_accuracy'] = False
         batch = dict(img=img, target=target, target_weight=tw, img_metas=metas)
 
@@ -428,7 +431,7 @@ def main():
         kname = f'vp_gemm_bf16<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi % 100}>'
         if epi == 100:   # the grouped launcher runs gemm192_kernel / gemm256_kernel<true, true, VP_EPI_F32>
             kname = 'vp_wgrad_grouped_bf16'
-        traffic, traffic_src = pmc_traffic(kname, dflop / dn)
+        traffic, traffic_src = pmc_traffic(f'{args.mode}_{args.model}{B}' + ('_exact' if args.exact else ''), kname, dflop / dn)
         out = {
             'metric': 'images/sec (256x192) ViTPose-B fwd+bwd at 1/2/4/8 GPUs; % bf16 MFMA roofline',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,

@@ -31,7 +31,21 @@ def load(path):
 
 
 def main():
-    fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('fetch_csv')
+    ap.add_argument('write_csv')
+    ap.add_argument('out')
+    ap.add_argument('--workload', default='', help='key prefix "<mode>_<model><batch>", e.g. train_B64: bench.py looks '
+                                                   'its dominant kernel up under "<workload>:<kernel>"')
+    ap.add_argument('--state', default='', help='tree state the passes were taken on (profiles/README.md), kept as _state')
+    ap.add_argument('--grouped-gflop', type=float, default=0.0,
+                    help='algorithmic GFLOP of one grouped weight-gradient launch of this run (bench.py prints it): a '
+                         'record taken on launches of another size is not used')
+    ap.add_argument('--merge', action='store_true', help='add to the records already in `out` instead of replacing them')
+    args = ap.parse_args()
+    fetch, write, out = load(args.fetch_csv), load(args.write_csv), args.out
+    pre = args.workload + ':' if args.workload else ''
     res = {}
     groups = {}
     for name in sorted(set(fetch) | set(write)):
@@ -60,7 +74,7 @@ def main():
             g[0] += n
             g[1] += fb * n
             g[2] += wb * n
-    # the grouped launcher's autotune probes both tile sizes once; the steady state runs one of them:
+    # the grouped launcher's autotune probes every tile schedule once; the steady state runs one of them:
     # report the variant with the most launches
     variants = [(res[k]['launches'], k) for k in res if re.match(r'gemm(192k?|256)_kernel<true, true, 5(?:, (?:true|false|\d+))*>', k)]
     if variants:
@@ -69,7 +83,21 @@ def main():
     for k, (n, fb, wb) in groups.items():
         res[k] = dict(launches=n, fetch_bytes_per_launch=round(fb / n), write_bytes_per_launch=round(wb / n),
                       hbm_bytes_per_launch=round((fb + wb) / n))
-    json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
+    if args.grouped_gflop and 'vp_wgrad_grouped_bf16' in res:
+        res['vp_wgrad_grouped_bf16']['gflop_per_launch'] = args.grouped_gflop
+    final = {}
+    if args.merge:
+        try:
+            final = json.load(open(out))
+        except (OSError, ValueError):
+            final = {}
+    final.update({pre + k: v for k, v in res.items()})
+    if args.state:
+        final['_state'] = args.state
+    final['_source'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of bench.py (one counter per run), reduced by '
+                        'tools/pmc_traffic.py: fetch bytes = 2 x FETCH_SIZE KiB (gfx950 counts 128-byte requests as 64), '
+                        'write bytes = WRITE_SIZE KiB')
+    json.dump(final, open(out, 'w'), indent=1, sort_keys=True)
     for k in sorted(res, key=lambda k: -res[k]['hbm_bytes_per_launch'] * res[k]['launches'])[:16]:
         v = res[k]
         print(f"{k[:70]:70s} x{v['launches']:5d}  fetch {v['fetch_bytes_per_launch'] / 1e6:8.1f} MB  write "

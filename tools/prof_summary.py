@@ -1,30 +1,37 @@
 #!/usr/bin/env python
-"""Per-kernel totals of a rocprofv3 run (rocpd sqlite output), restricted to the last `--steps`
-bench steps (identified by the memset that opens every training plan is not needed: the table is
-simply scaled by steps/(warmup+steps) launches per kernel name)."""
+"""Per-kernel totals of a rocprofv3 run (rocpd sqlite output) of bench.py, restricted to the TIMED steps.
+
+Every step of every bench mode (training step, eval forward) launches the patch-embedding im2col kernel exactly once, as
+its first kernel, so the i-th launch of that kernel marks the start of step i.  With --steps K (and --tail T = steps the
+bench runs AFTER its timed region, e.g. the parity forward passes or the reference-default iterations) the table covers
+the launches from the start of step (n - T - K) to the start of step (n - T): warm-up, the autotune probes of plan
+recording and the one survey step are outside."""
 import argparse
 import re
 import sqlite3
+
+MARKER = 'patch_im2col'
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('db')
     ap.add_argument('--csv', default='')
-    ap.add_argument('--steps', type=int, default=0, help='timed steps: only the last steps/(all) share of launches')
-    ap.add_argument('--all', type=int, default=0, help='warm-up + timed steps')
+    ap.add_argument('--steps', type=int, default=0, help='timed steps')
+    ap.add_argument('--tail', type=int, default=0, help='steps the bench runs after the timed region')
+    ap.add_argument('--all', type=int, default=0, help='(ignored; kept for old command lines)')
     args = ap.parse_args()
     cur = sqlite3.connect(args.db).cursor()
     rows = cur.execute('select name, start, end from kernels order by start').fetchall()
-    if args.steps and args.all:
-        # keep the launches after the (all - steps)/all point of the step sequence: find the
-        # start time of the adamw launch that ends warm-up
-        ad = [r for r in rows if 'adamw_kernel' in r[0]]
-        cut = ad[len(ad) - args.steps - 1][2] if len(ad) > args.steps else 0
-        rows = [r for r in rows if r[1] >= cut]
+    nsteps = 1
+    if args.steps:
+        marks = [r[1] for r in rows if MARKER in r[0]]
+        if len(marks) < args.steps + args.tail:
+            raise SystemExit(f'{len(marks)} steps in the trace, {args.steps} + {args.tail} asked for')
+        first = marks[len(marks) - args.tail - args.steps]
+        last = marks[len(marks) - args.tail] if args.tail else rows[-1][2] + 1
+        rows = [r for r in rows if first <= r[1] < last]
         nsteps = args.steps
-    else:
-        nsteps = 1
     agg = {}
     for n, s, e in rows:
         d = agg.setdefault(n, [0, 0, 1 << 62, 0])

@@ -18,7 +18,7 @@ namespace {
 // register footprint follows the actual row length (E = 768 -> 3 chunks) and occupancy stays high.
 // PAIR: y is a hi / lo pair array (rows of 2 E bf16: groups of 32 hi values followed by their 32 lo values,
 // hi = bf16(v), lo = bf16(v - hi)) of max(v, 0) when `relu` is set, else of v: the operand of an fp32-accurate GEMM.
-template <int CH, bool PAIR = false>
+template <int CH, bool PAIR, int R>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean_out,
@@ -37,110 +37,97 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         g[i] = ok ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
         b[i] = ok ? *reinterpret_cast<const f32x4*>(beta + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // A wave walks the row pairs (w, w + W), (w + 2 W, w + 3 W), ... (W = waves of the grid) through TWO register
-    // buffers: while pair p is reduced, normalised and stored, the loads of pair p + 1 are in flight, and pair p + 2 is
-    // requested as soon as p's registers are free -- reads and writes of a wave overlap, and so do those of the waves
-    // of a CU, instead of every wave of the chip loading, then every wave storing.
-    auto load_pair = [&](int row0, f32x4 (&v0)[CH], f32x4 (&v1)[CH]) {
-        const int row1 = row0 + nwaves;
-        const float* xr0 = x + (size_t)row0 * E;
-        const float* xr1 = x + (size_t)(row1 < M ? row1 : row0) * E;
+    // A wave walks groups of R rows (w + r W, r < R; then w + (R + r) W, ...; W = waves of the grid) through TWO
+    // register buffers: while group p is reduced, normalised and stored, the loads of group p + 1 are in flight, and
+    // group p + 2 is requested as soon as p's registers are free -- the reads and writes of a wave overlap, and so do
+    // those of the waves of a CU, instead of every wave of the chip loading and then every wave storing.  R = 2 rows
+    // per group where the registers allow it (rows of <= 1280 channels), else 1.
+    auto load_group = [&](int row0, f32x4 (&v)[R][CH]) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = lane + 64 * i;
-            const bool ok = c < nch;
-            v0[i] = ok ? *reinterpret_cast<const f32x4*>(xr0 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            v1[i] = ok ? *reinterpret_cast<const f32x4*>(xr1 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r * nwaves;
+            const float* xr = x + (size_t)(row < M ? row : row0) * E;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = lane + 64 * i;
+                v[r][i] = c < nch ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
-    auto process_pair = [&](int row0, f32x4 (&v0)[CH], f32x4 (&v1)[CH]) {
-        const int row1 = row0 + nwaves;
-        const bool has1 = row1 < M;
-        float s0 = 0.f, s1 = 0.f;
+    auto process_group = [&](int row0, f32x4 (&v)[R][CH]) {
+        float s[R], q[R], mu[R], rs[R];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            s0 += v0[i][0] + v0[i][1] + v0[i][2] + v0[i][3];
-            s1 += v1[i][0] + v1[i][1] + v1[i][2] + v1[i][3];
+        for (int r = 0; r < R; ++r) {
+            s[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) s[r] += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3];
         }
-        const float m0 = wave_sum(s0) * invE, m1 = wave_sum(s1) * invE;
-        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            if (lane + 64 * i < nch) {
+        for (int r = 0; r < R; ++r) mu[r] = wave_sum(s[r]) * invE;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d0 = v0[i][r] - m0, d1 = v1[i][r] - m1;
-                    q0 += d0 * d0;
-                    q1 += d1 * d1;
+        for (int r = 0; r < R; ++r) {
+            q[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (lane + 64 * i < nch) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[r][i][e] - mu[r];
+                        q[r] += d * d;
+                    }
                 }
             }
         }
-        const float r0 = rsqrtf(wave_sum(q0) * invE + eps), r1 = rsqrtf(wave_sum(q1) * invE + eps);
-        if (lane == 0) {
-            if (mean_out) {
-                mean_out[row0] = m0;
-                if (has1) mean_out[row1] = m1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) rs[r] = rsqrtf(wave_sum(q[r]) * invE + eps);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r * nwaves;
+            if (row >= M) break;
+            if (lane == 0) {
+                if (mean_out) mean_out[row] = mu[r];
+                if (rstd_out) rstd_out[row] = rs[r];
             }
-            if (rstd_out) {
-                rstd_out[row0] = r0;
-                if (has1) rstd_out[row1] = r1;
-            }
-        }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nch) {
-                f32x4 o0, o1;
+            for (int i = 0; i < CH; ++i) {
+                const int c = lane + 64 * i;
+                if (c < nch) {
+                    f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o0[r] = (v0[i][r] - m0) * r0 * g[i][r] + b[i][r];
-                    o1[r] = (v1[i][r] - m1) * r1 * g[i][r] + b[i][r];
-                }
-                if constexpr (PAIR) {
-                    if (relu) {
+                    for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mu[r]) * rs[r] * g[i][e] + b[i][e];
+                    if constexpr (PAIR) {
+                        if (relu) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            o0[r] = fmaxf(o0[r], 0.f);
-                            o1[r] = fmaxf(o1[r], 0.f);
+                            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
                         }
+                        const int pc = ((c >> 3) << 6) | ((c & 7) << 2);     // column 4c of the row in the pair layout
+                        const bf16x4 h = pack4(o[0], o[1], o[2], o[3]);
+                        bf16* p = y + (size_t)row * 2 * E + pc;
+                        *reinterpret_cast<bf16x4*>(p) = h;
+                        *reinterpret_cast<bf16x4*>(p + 32) = pack4(o[0] - (float)h[0], o[1] - (float)h[1],
+                                                                  o[2] - (float)h[2], o[3] - (float)h[3]);
+                    } else if (y) {
+                        *reinterpret_cast<bf16x4*>(y + (size_t)row * E + 4 * c) = pack4(o[0], o[1], o[2], o[3]);
                     }
-                    const int pc = ((c >> 3) << 6) | ((c & 7) << 2);     // column 4c of the row in the pair layout
-                    const bf16x4 h0 = pack4(o0[0], o0[1], o0[2], o0[3]), h1 = pack4(o1[0], o1[1], o1[2], o1[3]);
-                    bf16* p0 = y + (size_t)row0 * 2 * E + pc;
-                    *reinterpret_cast<bf16x4*>(p0) = h0;
-                    *reinterpret_cast<bf16x4*>(p0 + 32) = pack4(o0[0] - (float)h0[0], o0[1] - (float)h0[1],
-                                                               o0[2] - (float)h0[2], o0[3] - (float)h0[3]);
-                    if (has1) {
-                        bf16* p1 = y + (size_t)row1 * 2 * E + pc;
-                        *reinterpret_cast<bf16x4*>(p1) = h1;
-                        *reinterpret_cast<bf16x4*>(p1 + 32) = pack4(o1[0] - (float)h1[0], o1[1] - (float)h1[1],
-                                                                   o1[2] - (float)h1[2], o1[3] - (float)h1[3]);
-                    }
-                } else if (y) {
-                    *reinterpret_cast<bf16x4*>(y + (size_t)row0 * E + 4 * c) = pack4(o0[0], o0[1], o0[2], o0[3]);
-                    if (has1) *reinterpret_cast<bf16x4*>(y + (size_t)row1 * E + 4 * c) = pack4(o1[0], o1[1], o1[2], o1[3]);
-                }
-                if (y32) {
-                    *reinterpret_cast<f32x4*>(y32 + (size_t)row0 * E + 4 * c) = o0;
-                    if (has1) *reinterpret_cast<f32x4*>(y32 + (size_t)row1 * E + 4 * c) = o1;
+                    if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * E + 4 * c) = o;
                 }
             }
         }
     };
-    f32x4 a0[CH], a1[CH], b0[CH], b1[CH];
+    f32x4 bufA[R][CH], bufB[R][CH];
     int rowA = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rowA >= M) return;
-    int rowB = rowA + 2 * nwaves;
-    load_pair(rowA, a0, a1);
-    if (rowB < M) load_pair(rowB, b0, b1);
+    int rowB = rowA + R * nwaves;
+    load_group(rowA, bufA);
+    if (rowB < M) load_group(rowB, bufB);
     while (true) {
-        process_pair(rowA, a0, a1);
-        rowA += 4 * nwaves;
-        if (rowA < M) load_pair(rowA, a0, a1);
+        process_group(rowA, bufA);
+        rowA += 2 * R * nwaves;
+        if (rowA < M) load_group(rowA, bufA);
         if (rowB >= M) break;
-        process_pair(rowB, b0, b1);
-        rowB += 4 * nwaves;
-        if (rowB < M) load_pair(rowB, b0, b1);
+        process_group(rowB, bufB);
+        rowB += 2 * R * nwaves;
+        if (rowB < M) load_group(rowB, bufB);
         if (rowA >= M) break;
     }
 }
@@ -343,14 +330,14 @@ extern "C" int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats) {
     return ln_bwd_blocks(M, E, workspace_floats);
 }
 
-// workgroups of the forward kernel (tuning hook: VP_LN_FWD_BLOCKS)
-static int ln_fwd_block_cap() {
-    static const int cap = [] {
-        const char* e = getenv("VP_LN_FWD_BLOCKS");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 768;
-    }();
-    return cap;
+// Grid of the forward kernel for groups of R rows: at most the cap, and such that every wave gets the same number
+// of groups (6144 rows in single-row groups on 1024 workgroups would give half of the waves two rows, half one).
+static int ln_fwd_blocks(int M, int R) {
+    const int groups = (M + R - 1) / R;
+    const int cap = 1024;       // 4 resident workgroups per CU (measured: 768 and 1024 level, 512 and 1536 slower)
+    const int iters = (groups + 4 * cap - 1) / (4 * cap);
+    const int blocks = (groups + 4 * iters - 1) / (4 * iters);
+    return blocks < 1 ? 1 : blocks;
 }
 
 extern "C" int vp_layernorm_bwd_finalize(const vp_ln_partial* table_dev, int count, int E, hipStream_t stream) {
@@ -363,12 +350,16 @@ extern "C" int vp_layernorm_fwd(const float* x, const float* gamma, const float*
                                 float* mean, float* rstd, int M, int E, float eps, hipStream_t stream) {
     VP_CHECK_ARG(x && gamma && beta && (y_bf16 || y_f32));
     VP_CHECK_ARG(M > 0 && E > 0 && E % 4 == 0 && E <= 256 * 8);
-    int blocks = (M + 7) / 8;              // 4 waves x 2 rows per pass
-    const int cap = ln_fwd_block_cap();
-    if (blocks > cap) blocks = cap;
+    const int CHs = (E + 255) / 256;
+    const bool two = CHs <= 5;             // two rows per register buffer up to 1280 channels (measured faster at every ViTPose width)
+    const int blocks = ln_fwd_blocks(M, two ? 2 : 1);
 #define VP_LNF(CH)                                                                                                  \
-    hipLaunchKernelGGL((ln_fwd_kernel<CH, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_bf16, \
-                       y_f32, mean, rstd, M, E, eps, 0)
+    if (two && CH <= 5)                                                                                             \
+        hipLaunchKernelGGL((ln_fwd_kernel<CH, false, (CH <= 5 ? 2 : 1)>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, \
+                           (bf16*)y_bf16, y_f32, mean, rstd, M, E, eps, 0);                                        \
+    else                                                                                                            \
+        hipLaunchKernelGGL((ln_fwd_kernel<CH, false, 1>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta,      \
+                           (bf16*)y_bf16, y_f32, mean, rstd, M, E, eps, 0)
     switch ((E + 255) / 256) {
         case 1: VP_LNF(1); break;
         case 2: VP_LNF(2); break;
@@ -387,12 +378,10 @@ extern "C" int vp_layernorm_fwd_pair(const float* x, const float* gamma, const f
                                      int relu, int M, int E, float eps, hipStream_t stream) {
     VP_CHECK_ARG(x && gamma && beta && y_pair);
     VP_CHECK_ARG(M > 0 && E > 0 && E % 32 == 0 && E <= 256 * 8);
-    int blocks = (M + 7) / 8;
-    const int cap = ln_fwd_block_cap();
-    if (blocks > cap) blocks = cap;
+    const int blocks = ln_fwd_blocks(M, (E + 255) / 256 <= 5 ? 2 : 1);
 #define VP_LNP(CH)                                                                                                   \
-    hipLaunchKernelGGL((ln_fwd_kernel<CH, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (bf16*)y_pair, \
-                       y_f32, (float*)nullptr, (float*)nullptr, M, E, eps, relu)
+    hipLaunchKernelGGL((ln_fwd_kernel<CH, true, (CH <= 5 ? 2 : 1)>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, \
+                       (bf16*)y_pair, y_f32, (float*)nullptr, (float*)nullptr, M, E, eps, relu)
     switch ((E + 255) / 256) {
         case 1: VP_LNP(1); break;
         case 2: VP_LNP(2); break;
