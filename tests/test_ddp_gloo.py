@@ -64,6 +64,19 @@ def _worker(rank, world, port, depth, bpb, q):
         v = reduce_scalars(torch.tensor([float(rank), 2.0]))
         assert torch.allclose(v, torch.tensor([(world - 1) / 2.0, 2.0]))
         assert shard_batch(8 * world, rank, world) == (8 * rank, 8 * rank + 8)
+        # tile-schedule picks: every rank ends up with rank 0's, whatever it measured itself
+        from vitpose_amd import plan as plan_mod
+        from vitpose_amd.ddp import sync_tune_cache
+        plan_mod._TUNE_CACHE.clear()
+        plan_mod._TUNE_CACHE[('gemm', 12288, 768, 768, 0, 0, 2, True, False, 'cpu', 0, 0)] = 3 + rank
+        plan_mod._TUNE_CACHE[('wgrad_group', ((768, 768), (3072, 768)), 12288, 'cpu')] = 7 - 4 * rank
+        plan_mod._TUNE_CACHE[('gemm', 1, 2, 3, 0, 0, 0, False, False, 'cuda:7', 0, 0)] = 9      # another device: untouched
+        changed = sync_tune_cache(torch.device('cpu'))
+        assert changed == (rank != 0)
+        assert plan_mod._TUNE_CACHE[('gemm', 12288, 768, 768, 0, 0, 2, True, False, 'cpu', 0, 0)] == 3
+        assert plan_mod._TUNE_CACHE[('wgrad_group', ((768, 768), (3072, 768)), 12288, 'cpu')] == 7
+        assert plan_mod._TUNE_CACHE[('gemm', 1, 2, 3, 0, 0, 0, False, False, 'cuda:7', 0, 0)] == 9
+        assert sync_tune_cache(torch.device('cpu')) is False            # a second exchange changes nothing
         # the logged scalars of one iteration (detectors/base.py:38-76): averaged over ranks in ONE collective
         from vitpose_amd.models import TopDown
         calls, real = [], dist.all_reduce

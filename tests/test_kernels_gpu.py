@@ -964,3 +964,27 @@ def test_im2col3x3_and_col2im3x3_bit_exact(dev, B, H, W, C):
     want = torch.nn.functional.fold(fold_in, (H, W), 3, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, C)
     assert torch.equal(din.float(), want)
     assert torch.equal(dm.float(), want * (xcl.float() > 0))
+
+
+@pytest.mark.parametrize('E', [384, 768, 1024, 1280])
+def test_layernorm_fwd_row_result_is_independent_of_the_call_size(dev, E):
+    """A row's normalised values, mean and rstd are the same bits whatever the number of rows of the call, i.e.
+    whichever wave and register buffer of the pipelined kernel the row lands in (an image's heat maps must not depend on
+    the batch around it: tests/test_fullsize_gpu.py compares batch 64 with batch 2 bit for bit)."""
+    M = 12288
+    x = rnd((M, E), dev, 11, 3.0) + 0.5
+    gamma, beta = rnd((E,), dev, 12).abs() + 0.5, rnd((E,), dev, 13)
+    outs = []
+    for rows in (M, 1000, 384, 7, 2, 1):
+        y = torch.full((rows, E), float('nan'), device=dev, dtype=torch.bfloat16)
+        y32 = torch.full((rows, E), float('nan'), device=dev)
+        mean, rstd = torch.full((rows,), float('nan'), device=dev), torch.full((rows,), float('nan'), device=dev)
+        xr = x[:rows].contiguous()
+        run(lambda p: p.layernorm_fwd(xr, gamma, beta, y, y32, mean, rstd, rows, E))
+        outs.append((rows, y, y32, mean, rstd))
+    _, y0, y320, mean0, rstd0 = outs[0]
+    ref = torch.nn.functional.layer_norm(x, (E,), gamma, beta, 1e-6)
+    torch.testing.assert_close(y320, ref, rtol=1e-5, atol=1e-5)
+    for rows, y, y32, mean, rstd in outs[1:]:
+        assert torch.equal(y, y0[:rows]) and torch.equal(y32, y320[:rows]), rows
+        assert torch.equal(mean, mean0[:rows]) and torch.equal(rstd, rstd0[:rows]), rows

@@ -55,6 +55,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
     };
     auto process_group = [&](int row0, f32x4 (&v)[R][CH]) {
+        // Every row must get the same arithmetic whichever slot r of a group it lands in (an image's result may not
+        // depend on the size of the batch around it): no contraction left to the compiler's choice -- it had fused
+        // the squares of one row of a pair and not of the other -- the fused operations are written out.
+#pragma clang fp contract(off)
         float s[R], q[R], mu[R], rs[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float d = v[r][i][e] - mu[r];
-                        q[r] += d * d;
+                        q[r] = __builtin_fmaf(d, d, q[r]);
                     }
                 }
             }
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 if (c < nch) {
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mu[r]) * rs[r] * g[i][e] + b[i][e];
+                    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf((v[r][i][e] - mu[r]) * rs[r], g[i][e], b[i][e]);
                     if constexpr (PAIR) {
                         if (relu) {
 #pragma unroll

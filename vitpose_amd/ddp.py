@@ -166,6 +166,20 @@ class GradBuckets:
         return 1.0 / self.world
 
 
+def sync_tune_cache(device, group=None) -> bool:
+    """Every rank times its GEMM tile schedules on its own GPU when it records a plan, and two GPUs can disagree on
+    a close call; ranks that run different schedules finish their steps at different times and the fastest waits in
+    every all-reduce.  Rank 0's picks are therefore broadcast and adopted by all (a collective: every rank calls it at
+    the same point, right after recording a plan).  Returns True when this rank's picks changed (its plan has to be
+    recorded again, now without timing anything)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return False
+    from .plan import export_tune_cache, import_tune_cache
+    box = [export_tune_cache(device) if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return import_tune_cache(box[0], device)
+
+
 def reduce_scalars(values: torch.Tensor, group=None) -> torch.Tensor:
     """Average a small tensor of logged scalars over ranks (one collective for all of them)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

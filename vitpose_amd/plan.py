@@ -74,6 +74,24 @@ def _pick_fastest(cands, rounds=3):
     return min(best, key=best.get)
 
 
+def export_tune_cache(device):
+    """The launch-shape picks recorded for `device`, keyed without the device (ranks of one job name their GPUs
+    differently)."""
+    d = str(device)
+    return {tuple('<device>' if x == d else x for x in k): v for k, v in _TUNE_CACHE.items() if d in k}
+
+
+def import_tune_cache(picks, device):
+    """Adopt another process's picks (from export_tune_cache) for `device`; True if any pick of this process changed."""
+    d, changed = str(device), False
+    for k, v in picks.items():
+        kk = tuple(d if x == '<device>' else x for x in k)
+        if _TUNE_CACHE.get(kk) != v:
+            _TUNE_CACHE[kk] = v
+            changed = True
+    return changed
+
+
 _ZERO_PAGES = {}
 
 

@@ -151,7 +151,7 @@ class PoseEngine:
         return heat.clone() if copy_out else heat
 
     # ---- training ----
-    def _train_plan(self, B):
+    def _train_plan(self, B, _tuned=False):
         key = ('train', B)
         if key not in self.plans:
             ws = self.ws_train
@@ -203,6 +203,13 @@ class PoseEngine:
             if comm is not None:
                 comm.finish(plan)
             self.plans[key] = (plan, io)
+            if comm is not None and not _tuned:
+                # all ranks run the tile schedules rank 0 measured (see ddp.sync_tune_cache); a rank whose own picks
+                # differed records the plan once more, from the shared picks
+                from .ddp import sync_tune_cache
+                if sync_tune_cache(self.device, comm.group):
+                    del self.plans[key]
+                    return self._train_plan(B, _tuned=True)
         return self.plans[key]
 
     def scale_dheat(self, dheat: torch.Tensor, scale: torch.Tensor):
