@@ -212,6 +212,8 @@ def main():
     ap.add_argument('--exact', action='store_true',
                     help='--mode infer only: the fp32-accurate evaluation path (test_cfg fp32_exact: split3 GEMMs on '
                          'hi/lo bf16 pairs, everything else f32) instead of the bf16 path')
+    ap.add_argument('--fold-ln', action='store_true',
+                    help='--mode infer only: test_cfg fold_layernorm (norm1 / norm2 of every Block folded into qkv / fc1)')
     args = ap.parse_args()
 
     if os.environ.get('VITPOSE_BENCH_WATCHDOG'):        # debugging aid: dump every thread's stack and exit when stuck
@@ -253,6 +255,10 @@ def main():
         if args.mode != 'infer':
             raise SystemExit('--exact is an evaluation path: use it with --mode infer')
         cfg['test_cfg']['fp32_exact'] = True
+    if args.fold_ln:
+        if args.mode != 'infer' or args.exact:
+            raise SystemExit('--fold-ln is an option of the bf16 evaluation path: use it with --mode infer')
+        cfg['test_cfg']['fold_layernorm'] = True
     model = build_posenet(cfg).to(dev)
     metas = [dict(dataset_idx=i % 6) for i in range(args.batch)] if args.plus else None
     loss_keys = ['main_stream_loss'] + [f'{i}_loss' for i in range(1, 6)] if args.plus else ['heatmap_loss']
@@ -310,12 +316,14 @@ def main():
         def step():
             with torch.no_grad():
                 return model.forward_dummy(img)
-        plan_of = lambda: eng.plans[('exact' if args.exact else 'infer', B)][0]  # noqa: E731
+        plan_of = lambda: eng.plans[('exact', B) if args.exact else ('infer', B, True) if args.fold_ln else ('infer', B)][0]  # noqa: E731
         gflop = m['fwd_gflop']
         what = (f'ViTPose-{args.model} 256x192 classic-decoder inference (one eval forward, flip_test off as in '
                 f'tools/analysis/speed_test.py) via TopDown.forward_dummy, batch {B}/GPU, random-init weights')
         if args.exact:
             what += ', fp32-accurate path (test_cfg fp32_exact)'
+        if args.fold_ln:
+            what += ', LayerNorms folded into qkv / fc1 (test_cfg fold_layernorm)'
 
     def group(timers):
         groups = {}
@@ -431,7 +439,7 @@ def main():
         kname = f'vp_gemm_bf16<{"true" if xk else "false"}, {"true" if yk else "false"}, {epi % 100}>'
         if epi == 100:   # the grouped launcher runs gemm192_kernel / gemm256_kernel<true, true, VP_EPI_F32>
             kname = 'vp_wgrad_grouped_bf16'
-        traffic, traffic_src = pmc_traffic(f'{args.mode}_{args.model}{B}' + ('_exact' if args.exact else ''), kname, dflop / dn)
+        traffic, traffic_src = pmc_traffic(f'{args.mode}_{args.model}{B}' + ('_exact' if args.exact else '') + ('_fold' if args.fold_ln else ''), kname, dflop / dn)
         out = {
             'metric': 'images/sec (256x192) ViTPose-B fwd+bwd at 1/2/4/8 GPUs; % bf16 MFMA roofline',
             'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,

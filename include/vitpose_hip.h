@@ -30,7 +30,7 @@ typedef void* vp_stream_t;
 typedef hipStream_t vp_stream_t;
 #endif
 
-#define VP_ABI_VERSION 3
+#define VP_ABI_VERSION 4
 int vp_abi_version(void);
 /* gfx target the library was compiled for, e.g. "gfx950". */
 const char* vp_build_arch(void);
@@ -118,9 +118,27 @@ typedef struct vp_gemm_args {
      * pair_act 0 none, 1 exact-erf GELU, 2 ReLU).  route_* are honoured with VP_EPI_RESID_F32 (route_delta in pair
      * elements). */
     int split3; int pair_act;
+    /* optional LayerNorm fold (evaluation only: the weights are fixed).  Block.forward (vit.py:137-140) feeds
+     * norm1(x) to attn.qkv and norm2(x) to mlp.fc1; with W' = W diag(gamma),
+     *   LN(x) W^T + b = rstd (x W'^T - mean s) + c,   s[n] = sum_k W'[n][k],   c = W beta + b,
+     * so the Linear can read the raw residual stream and the LayerNorm launch (and its f32 re-read of the stream)
+     * disappears.  PRODUCER (ln_stats_out != NULL, VP_EPI_RESID_F32, tile_mode 2 / 3 / 6): besides `out` it writes
+     * the bf16 copy of the stream to out2 [M][ldo] and, per row and column tile, the sum and the sum of squares of
+     * the tile's columns to ln_stats_out [M][ln_slots][2] (ln_slots = vp_gemm_ln_slots(N, tile_mode)).  CONSUMER
+     * (ln_stats != NULL, VP_EPI_BF16 / VP_EPI_GELU, any tile_mode but 5): x = that bf16 copy, y = W' (bf16),
+     * colscale = s, bias = c, K = the normalised width; mean / rstd of a row come from its ln_slots pairs (summed in
+     * slot order: deterministic, independent of the batch), variance = E[x^2] - mean^2 in f32, eps = ln_eps. */
+    float* ln_stats_out; const float* ln_stats; int ln_slots; float ln_eps;
 } vp_gemm_args;
 
 int vp_gemm_bf16(const vp_gemm_args* args, vp_stream_t stream);
+/* column tiles (= statistics pairs per row) of a folded-LayerNorm producer on tile_mode 2 / 3 / 6; 0 otherwise */
+int vp_gemm_ln_slots(int N, int tile_mode);
+/* The folded weights of one Linear behind a LayerNorm (see vp_gemm_args.ln_stats): W [N][K] f32, gamma / beta [K],
+ * bias [N] or NULL -> Wg [N][K] bf16 = bf16(W[n][k] gamma[k]), s [N] = sum_k Wg[n][k] (of the ROUNDED weights: the
+ * mean term then cancels exactly what the matrix cores accumulate), c [N] = sum_k W[n][k] beta[k] + bias[n]. */
+int vp_ln_fold_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* s,
+                       float* c, int N, int K, vp_stream_t stream);
 /* out[i] (+)= sum_z slab[z*stride + i], i < n: the deterministic reduction of the split-K slabs
  * (weight gradients; replaces autograd's dW accumulation of nn.Linear / conv layers). */
 int vp_splitk_reduce(const float* slab, int nsplit, long stride, size_t n, float* out, int accumulate,

@@ -988,3 +988,110 @@ def test_layernorm_fwd_row_result_is_independent_of_the_call_size(dev, E):
     for rows, y, y32, mean, rstd in outs[1:]:
         assert torch.equal(y, y0[:rows]) and torch.equal(y32, y320[:rows]), rows
         assert torch.equal(mean, mean0[:rows]) and torch.equal(rstd, rstd0[:rows]), rows
+
+
+# ------------------------------------------------------------------ LayerNorm folded into the next Linear (evaluation)
+@pytest.mark.parametrize('mode', [2, 3, 6])
+@pytest.mark.parametrize('M,N,K', [(768, 768, 768), (1000, 1280, 512), (384, 1024, 3072)])
+def test_gemm_residual_epilogue_with_layernorm_statistics(dev, mode, M, N, K):
+    """The producer side of the fold: a VP_EPI_RESID_F32 launch that also writes the bf16 copy of the stream and,
+    per row and column tile, the sum and the sum of squares -- the f32 stream itself is bit-identical to the plain
+    launch, the copy is its rounding, the statistics add up to the row's (ragged rows and column tiles included)."""
+    from vitpose_amd import _lib
+    X, Y = rnd((M, K), dev, 3).bfloat16(), rnd((N, K), dev, 4, 0.05).bfloat16()
+    bias, resid = rnd((N,), dev, 5), rnd((M, N), dev, 6, 2.0)
+    plain = torch.full((M, N), float('nan'), device=dev)
+    run(lambda p: p.gemm(X, Y, plain, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, resid=resid,
+                         epilogue=_lib.VP_EPI_RESID_F32, tile_mode=mode))
+    out = torch.full((M, N), float('nan'), device=dev)
+    xb = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+    stats = torch.full((M, (N + 127) // 128, 2), float('nan'), device=dev)
+    got = {}
+    run(lambda p: got.update(slots=p.gemm(X, Y, out, M, N, K, ldx=K, ldy=K, ldo=N, bias=bias, resid=resid, out2=xb,
+                                         epilogue=_lib.VP_EPI_RESID_F32, tile_mode=mode, ln_stats_out=stats)))
+    slots = got['slots']
+    assert slots == -(-N // {2: 256, 3: 192, 6: 128}[mode])
+    assert torch.equal(out, plain) and torch.equal(xb, out.bfloat16())
+    st = stats.view(-1)[:M * slots * 2].view(M, slots, 2).double()      # [M][slots][2], compact in the allocation
+    assert torch.isfinite(st).all()
+    torch.testing.assert_close(st[..., 0].sum(1), out.double().sum(1), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st[..., 1].sum(1), (out.double() ** 2).sum(1), rtol=1e-5, atol=1e-3)
+
+
+def _folded_case(dev, kind, M=960, E=768, N=1536, seed=20):
+    """A residual stream [M][E] with the statistics a trained ViT shows (`outliers`: a few channels carry values
+    30 x the rest) or with a common offset many times its spread (`offset`: the case in which E[x^2] - mean^2 and
+    the bf16 rounding of the raw stream lose what the plain path keeps), LayerNorm parameters and a Linear."""
+    x = rnd((M, E), dev, seed)
+    if kind == 'outliers':
+        x[:, ::97] = x[:, ::97] * 3 + 30.0
+        x += rnd((M, 1), dev, seed + 1, 0.5)
+    elif kind == 'offset':
+        x += 10.0
+    gamma, beta = rnd((E,), dev, seed + 2).abs() + 0.5, rnd((E,), dev, seed + 3, 0.3)
+    W, b = rnd((N, E), dev, seed + 4, 0.04), rnd((N,), dev, seed + 5, 0.1)
+    ref = torch.nn.functional.layer_norm(x.double(), (E,), gamma.double(), beta.double(), 1e-6) @ W.double().t() + b.double()
+    return x, gamma, beta, W, b, ref
+
+
+@pytest.mark.parametrize('mode', [1, 2, 3, 4, 6])
+@pytest.mark.parametrize('kind', ['plain', 'outliers'])
+def test_gemm_consumes_folded_layernorm(dev, mode, kind):
+    """The consumer side: x W'^T on the bf16 copy of the RAW stream with W' = W diag(gamma), finished in the epilogue
+    as rstd (acc - mean s) + c, against LayerNorm (f64) followed by the Linear -- as accurate as the plain bf16 path
+    (LayerNorm launch, then the GEMM on its bf16 output), also when a few channels carry values 30 x the others (the
+    massive activations of trained transformers), on every tile schedule, with and without the GELU."""
+    from vitpose_amd import _lib
+    M, E, N = 960, 768, 1536
+    x, gamma, beta, W, b, ref = _folded_case(dev, kind, M, E, N)
+    slots = 4
+    stats = torch.stack([x.view(M, slots, E // slots).sum(2), (x.view(M, slots, E // slots) ** 2).sum(2)], dim=2).contiguous()
+    wg = torch.empty(N, E, device=dev, dtype=torch.bfloat16)
+    s, c = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    run(lambda p: p.ln_fold_weights(W, gamma, beta, b, wg, s, c, N, E))
+    assert torch.equal(wg, (W * gamma).bfloat16())
+    torch.testing.assert_close(s, wg.float().sum(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(c, (W.double() @ beta.double() + b.double()).float(), rtol=1e-5, atol=1e-5)
+    xb = x.bfloat16()
+    xn = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.layernorm_fwd(x, gamma, beta, xn, None, None, None, M, E))
+
+    def rel(a, r):
+        return ((a.double() - r).norm() / r.norm()).item()
+    for epi, fin in ((_lib.VP_EPI_BF16, lambda t: t), (_lib.VP_EPI_GELU, torch.nn.functional.gelu)):
+        folded = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+        run(lambda p: p.gemm(xb, wg, folded, M, N, E, ldx=E, ldy=E, ldo=N, colscale=s, bias=c, epilogue=epi,
+                             tile_mode=mode, ln_stats=(stats, slots)))
+        plain = torch.full((M, N), float('nan'), device=dev, dtype=torch.bfloat16)
+        run(lambda p: p.gemm(xn, W.bfloat16(), plain, M, N, E, ldx=E, ldy=E, ldo=N, bias=b, epilogue=epi, tile_mode=mode))
+        want = fin(ref)
+        ef, ep = rel(folded, want), rel(plain, want)
+        print(f'folded LayerNorm, {kind}, tile_mode {mode}, epilogue {epi}: folded {ef:.2e}, plain {ep:.2e}')
+        assert not torch.isnan(folded.float()).any()
+        assert ef < 1.3 * ep + 1e-4, (ef, ep)
+
+
+def test_folded_layernorm_loses_precision_under_a_common_offset(dev):
+    """Where the fold is WORSE, measured so that the limit is on record: a stream whose rows sit at 10 x their spread
+    (mean / std = 10).  The raw stream rounded to bf16 keeps 8 bits of a number ten times larger than what the
+    LayerNorm keeps, so the folded product is ~10 x less accurate than the plain path there.  Trained ViT streams are
+    not of this kind (their large values sit in a few channels: the `outliers` case above, where both paths agree);
+    `VITPOSE_LN_FOLD=0` selects the plain path."""
+    from vitpose_amd import _lib
+    M, E, N = 960, 768, 1536
+    x, gamma, beta, W, b, ref = _folded_case(dev, 'offset', M, E, N)
+    stats = torch.stack([x.view(M, 4, E // 4).sum(2), (x.view(M, 4, E // 4) ** 2).sum(2)], dim=2).contiguous()
+    wg = torch.empty(N, E, device=dev, dtype=torch.bfloat16)
+    s, c = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    run(lambda p: p.ln_fold_weights(W, gamma, beta, b, wg, s, c, N, E))
+    folded = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.gemm(x.bfloat16(), wg, folded, M, N, E, ldx=E, ldy=E, ldo=N, colscale=s, bias=c, tile_mode=3,
+                         ln_stats=(stats, 4)))
+    xn = torch.empty(M, E, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.layernorm_fwd(x, gamma, beta, xn, None, None, None, M, E))
+    plain = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    run(lambda p: p.gemm(xn, W.bfloat16(), plain, M, N, E, ldx=E, ldy=E, ldo=N, bias=b, tile_mode=3))
+    ef = ((folded.double() - ref).norm() / ref.norm()).item()
+    ep = ((plain.double() - ref).norm() / ref.norm()).item()
+    print(f'common offset 10 sigma: folded {ef:.2e}, plain {ep:.2e}')
+    assert ep < 5e-3 and ef < 12 * ep and ef < 5e-2

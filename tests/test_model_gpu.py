@@ -518,3 +518,37 @@ def test_empty_batch_is_rejected(dev):
     with pytest.raises(ValueError):
         eng.forward_backward(torch.zeros(0, 3, 256, 192, device=dev), torch.zeros(0, 17, 64, 48, device=dev),
                              torch.zeros(0, 17, 1, device=dev))
+
+
+@pytest.mark.parametrize('name,B', [('S', 2), ('B', 4), ('H', 3)])
+def test_folded_layernorm_eval_matches_plain_path_and_oracle(dev, name, B):
+    """Evaluation with norm1 / norm2 of every Block folded into qkv / fc1 (infer(fold_ln=True), test_cfg fold_layernorm):
+    the same network -- heat maps as close to the fp32 oracle as the plain path's, and within bf16 rounding of them; a
+    weight update reaches the folded weights; an image's result does not depend on its batch (the statistics are summed
+    in an order the width alone fixes)."""
+    vcfg = O.vit_cfg(name)
+    hc = O.classic_head_cfg(vcfg['embed_dim'])
+    bb, hd = O.synth_vit_weights(vcfg, seed=30), O.synth_head_weights(hc, seed=31)
+    img, _, _ = O.synth_batch(max(B, 8), seed=32)
+    with torch.no_grad():
+        ref = O.topdown_forward(bb, hd, img[:B], vcfg, hc)
+    eng = make_engine(vcfg, hc, bb, hd, dev)
+    x = img.to(dev)
+    plain, folded = eng.infer(x[:B]).cpu(), eng.infer(x[:B], fold_ln=True).cpu()
+    # no LayerNorm launch but the last one
+    names = [c[0] for c in eng.plans[('infer', B, True)][0].calls]
+    assert names.count('vp_layernorm_fwd') == 1 and [c[0] for c in eng.plans[('infer', B)][0].calls].count('vp_layernorm_fwd') > 2
+    # batch-independent, bit for bit: batch 1 (no timing-based schedule choice applies) and batch 8 (it does)
+    assert torch.equal(eng.infer(x[:1], fold_ln=True).cpu(), folded[:1])
+    assert torch.equal(eng.infer(x, fold_ln=True).cpu()[:B], folded)
+    r_plain, r_fold = relerr(plain, ref)[0], relerr(folded, ref)[0]
+    print(f'ViTPose-{name} x {B}: heat maps vs oracle: plain {r_plain:.2e}, folded {r_fold:.2e}; '
+          f'folded vs plain {relerr(folded, plain)[0]:.2e}')
+    assert meas(f'{name} folded eval rel', r_fold) < max(1.25 * r_plain, 9e-3) and relerr(folded, plain)[0] < 8e-3
+    # new weights reach the folded copies
+    sd = eng.state_dict()
+    sd['backbone.blocks.0.norm1.weight'] = sd['backbone.blocks.0.norm1.weight'] * 1.5
+    sd['backbone.blocks.1.mlp.fc1.bias'] = sd['backbone.blocks.1.mlp.fc1.bias'] + 0.3
+    eng.load_state_dict(sd)
+    changed, want = eng.infer(x[:B], fold_ln=True).cpu(), eng.infer(x[:B]).cpu()
+    assert relerr(changed, folded)[0] > 1e-2 and relerr(changed, want)[0] < 8e-3

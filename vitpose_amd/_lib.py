@@ -10,7 +10,7 @@ import torch  # noqa: F401  (first: the library must bind to the HIP runtime tor
 from ctypes import POINTER, Structure, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3   # VP_ABI_VERSION of include/vitpose_hip.h this binding was written for
+ABI_VERSION = 4   # VP_ABI_VERSION of include/vitpose_hip.h this binding was written for
 LIB_PATH = os.environ.get('VITPOSE_HIP_LIB') or os.path.join(_HERE, 'lib', 'libvitpose_hip.so')
 
 VP_EPI_BF16, VP_EPI_GELU, VP_EPI_RESID_F32, VP_EPI_DGELU = 0, 1, 2, 3
@@ -36,6 +36,7 @@ class GemmArgs(Structure):
         ('route_expert', c_void_p), ('route_delta', c_void_p), ('route_bias_delta', c_void_p), ('route_split', c_int),
         ('gather16_H', c_int), ('gather16_W', c_int), ('gather16_C', c_int), ('gather16_zero', c_void_p),
         ('split3', c_int), ('pair_act', c_int),
+        ('ln_stats_out', c_void_p), ('ln_stats', c_void_p), ('ln_slots', c_int), ('ln_eps', c_float),
     ]
 
 
@@ -55,6 +56,7 @@ class LnPartial(Structure):
 
 SIGNATURES = {
     'vp_gemm_bf16': [POINTER(GemmArgs), P],
+    'vp_ln_fold_weights': [P, P, P, P, P, P, P, c_int, c_int, P],
     'vp_deconv_fwd_bf16': [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P],
     'vp_deconv_weight_prep': [P, P, P, c_int, c_int, P],
     'vp_deconv_dgrad_bf16': [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
@@ -67,6 +69,7 @@ SIGNATURES = {
     'vp_layernorm_bwd_finalize': [P, c_int, c_int, P],
     'vp_layernorm_bwd_static': [P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P],
     'vp_layernorm_bwd_blocks': [c_int, c_int, c_size_t],       # host-side helper: no stream argument
+    'vp_gemm_ln_slots': [c_int, c_int],                        # host-side helper: no stream argument
     'vp_attention_fwd': [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     'vp_attention_bwd': [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     'vp_patch_im2col': [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],

@@ -107,7 +107,55 @@ struct Epi {
     int row_div, row_hi, row_lo, row_off;  // out row = (i / div) * hi + (i % div) * lo + off when div > 0
     long split_stride;                     // elements between the K-slice slabs of VP_EPI_SPLITK_F32
     int pair_act;                          // VP_EPI_PAIR: 0 none, 1 exact GELU, 2 ReLU
+    // LayerNorm fold (evaluation).  Consumer (VP_EPI_BF16 / GELU, ln_stats set): X holds the RAW residual stream in
+    // bf16 and Y the weights scaled by gamma, so out = rstd (acc - mean s) + c with s = colscale, c = bias, and mean /
+    // rstd of a row from its ln_slots pairs (sum, sum of squares) over the ln_inv_n^-1 channels.  Producer
+    // (VP_EPI_RESID_F32, ln_stats_out set): besides the f32 stream, writes its bf16 copy to out2 and one (sum, sum
+    // of squares) pair per row and column tile.
+    const float* ln_stats;
+    float* ln_stats_out;
+    int ln_slots;
+    float ln_inv_n, ln_eps;
 };
+
+// mean and rstd of the rows a lane holds (fragment row a = row row0 + 16 a + li), from the producer's per-tile sums.
+// The four lanes that hold a row (one per lane group g) each fetch the slots j = g, g + 4, ... -- all loads of a call
+// are issued before the first is used -- and the partial sums meet by two shuffles: a fixed order of additions, so a
+// row's statistics do not depend on the batch around it.
+constexpr int LN_MAX_SLOTS = 12;       // column tiles of the producer: 1280 channels on 128-wide tiles are 10
+
+template <int NA>
+__device__ __forceinline__ void ln_row_stats(const Epi& e, float (&mu)[NA], float (&rsd)[NA], int row0, int g, int li,
+                                             int M) {
+    float2 t[NA][LN_MAX_SLOTS / 4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const int row_raw = row0 + a * 16 + li;
+        const int row = row_raw < M ? row_raw : M - 1;
+        const float2* p = reinterpret_cast<const float2*>(e.ln_stats) + (size_t)row * e.ln_slots;
+#pragma unroll
+        for (int j = 0; j < LN_MAX_SLOTS / 4; ++j) {
+            const int slot = g + 4 * j;
+            t[a][j] = slot < e.ln_slots ? p[slot] : float2{0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        float sum = t[a][0].x, sq = t[a][0].y;
+#pragma unroll
+        for (int j = 1; j < LN_MAX_SLOTS / 4; ++j) {
+            sum += t[a][j].x;
+            sq += t[a][j].y;
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sq += __shfl_xor(sq, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        const float m = sum * e.ln_inv_n;
+        mu[a] = m;
+        rsd[a] = rsqrtf(fmaxf(sq * e.ln_inv_n - m * m, 0.f) + e.ln_eps);
+    }
+}
 
 // Epilogue of one wave's 64x64 sub-tile.  All per-column (bias / colscale) and per-row
 // (DropPath scale, residual / position row pointer, remapped output row) operands are fetched
@@ -141,9 +189,11 @@ __device__ __forceinline__ void load_addend(const Epi& e, f32x4 (&pre)[FM][FN], 
     }
 }
 
-template <int EPI, int FM, int FN>
-__device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
-                                             int M, int N, int slice = 0, const f32x4 (*pre)[FN] = nullptr) {
+// LNF: the consumer side of a folded LayerNorm (VP_EPI_BF16 / GELU with Epi::ln_stats): a code path of its own, so
+// that the ordinary epilogue keeps the registers (and the instruction stream) it has without the fold.
+template <int EPI, int FM, int FN, bool LNF>
+__device__ __forceinline__ void run_epilogue_impl(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
+                                                  int M, int N, int slice, const f32x4 (*pre)[FN]) {
     const int g = lane >> 4, li = lane & 15;
     int col[FN];
     bool cok[FN];
@@ -162,12 +212,14 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
             for (int b = 0; b < FN; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
         }
     }
-    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU || EPI == VP_EPI_PAIR) {
+    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU || EPI == VP_EPI_PAIR || LNF) {
         if (e.colscale) {
 #pragma unroll
             for (int b = 0; b < FN; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
         }
     }
+    float mu[LNF ? FM : 1], rsd[LNF ? FM : 1];
+    if constexpr (LNF) ln_row_stats<FM>(e, mu, rsd, row0, g, li, M);
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
         const int row_raw = row0 + a * 16 + li;
@@ -181,7 +233,9 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
             bf16* o2 = EPI == VP_EPI_GELU && e.out2 ? (bf16*)e.out2 + orow * e.ldo : nullptr;
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
-                f32x4 v = acc[a][b] * cs[b] + bias[b];
+                f32x4 v;
+                if constexpr (LNF) v = (acc[a][b] - cs[b] * mu[a]) * rsd[a] + bias[b];
+                else v = acc[a][b] * cs[b] + bias[b];
                 const bool ok = rok && cok[b];
                 if constexpr (EPI == VP_EPI_GELU) {
                     if (o2 && VP_ST_OK(ok)) *reinterpret_cast<bf16x4*>(o2 + col[b]) = pack4(v[0], v[1], v[2], v[3]);
@@ -260,6 +314,15 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
     }
 }
 
+template <int EPI, int FM, int FN>
+__device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
+                                             int M, int N, int slice = 0, const f32x4 (*pre)[FN] = nullptr) {
+    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU) {
+        if (e.ln_stats) return run_epilogue_impl<EPI, FM, FN, true>(e, acc, row0, col0, lane, M, N, slice, pre);
+    }
+    run_epilogue_impl<EPI, FM, FN, false>(e, acc, row0, col0, lane, M, N, slice, pre);
+}
+
 // bf16 outputs: a lane of the accumulator layout owns 4 consecutive columns (8 bytes), and 8-byte
 // row-scattered stores leave the chip at ~2.5 TB/s (store-issue bound).  The wave's 64 x 64 block is
 // therefore transposed through a wave-private LDS region (row pitch 144 B: conflict-free 8-byte
@@ -268,9 +331,10 @@ __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN],
 constexpr int STG_PITCH = 144;
 constexpr int STG_BYTES = 64 * STG_PITCH;
 
-template <int EPI, int FM, int FN = 4, int RG = 4>
-__device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
-                                                    int M, int N, char* stg) {
+// RAW: the values leave as they are (no bias / scale / activation): the bf16 copy of an f32 output.
+template <int EPI, int FM, int FN, int RG, bool RAW, bool LNF>
+__device__ __forceinline__ void run_epilogue_staged_impl(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
+                                                         int M, int N, char* stg) {
     constexpr int PITCH = FN * 32 + 16, CHUNKS = FN * 2, ROWS = RG * 16;
     static_assert(FM % RG == 0, "row fragments must split evenly into flush groups");
     static_assert(EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU || EPI == VP_EPI_DGELU ||
@@ -285,13 +349,13 @@ __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[F
         bias[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         cs[b] = f32x4{1.f, 1.f, 1.f, 1.f};
     }
-    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU) {
+    if constexpr (!RAW && (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_SCALE_RELU)) {
         if (e.bias) {
 #pragma unroll
             for (int b = 0; b < FN; ++b) bias[b] = *reinterpret_cast<const f32x4*>(e.bias + col[b]);
         }
     }
-    if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU) {
+    if constexpr (!RAW && (EPI == VP_EPI_BF16 || EPI == VP_EPI_SCALE_RELU || LNF)) {
         if (e.colscale) {
 #pragma unroll
             for (int b = 0; b < FN; ++b) cs[b] = *reinterpret_cast<const f32x4*>(e.colscale + col[b]);
@@ -300,6 +364,8 @@ __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[F
     constexpr int NPASS = EPI == VP_EPI_GELU ? 2 : 1;   // GELU: pass 0 = pre-activation copy (out2), pass 1 = out
 #pragma unroll
     for (int half = 0; half < FM / RG; ++half) {
+        float mu[LNF ? RG : 1], rsd[LNF ? RG : 1];      // folded LayerNorm: statistics of this flush group's rows
+        if constexpr (LNF) ln_row_stats<RG>(e, mu, rsd, row0 + half * RG * 16, g, li, M);
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             if (EPI == VP_EPI_GELU && pass == 0 && !e.out2) continue;
@@ -325,8 +391,11 @@ __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[F
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = (float)u[b][r] > 0.f ? v[r] : 0.f;
                         }
+                    } else if constexpr (RAW) {
+                        v = acc[A][b];
                     } else {
-                        v = acc[A][b] * cs[b] + bias[b];
+                        if constexpr (LNF) v = (acc[A][b] - cs[b] * mu[a]) * rsd[a] + bias[b];
+                        else v = acc[A][b] * cs[b] + bias[b];
                         if (EPI == VP_EPI_GELU && pass == 1) {
                             v = gelu_erf(v);
                         }
@@ -355,6 +424,95 @@ __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[F
             }
         }
     }
+}
+
+template <int EPI, int FM, int FN = 4, int RG = 4, bool RAW = false>
+__device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
+                                                    int M, int N, char* stg) {
+    if constexpr (!RAW && (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU)) {
+        if (e.ln_stats) return run_epilogue_staged_impl<EPI, FM, FN, RG, false, true>(e, acc, row0, col0, lane, M, N, stg);
+    }
+    run_epilogue_staged_impl<EPI, FM, FN, RG, RAW, false>(e, acc, row0, col0, lane, M, N, stg);
+}
+
+// VP_EPI_RESID_F32 with the LayerNorm fold's by-products (kernels whose four column waves `wc` of a row group `grp`
+// share their rows): the f32 stream as usual, then per row the sum and the sum of squares of the tile's columns --
+// lane sums, the four lane groups, then the four waves through LDS in a fixed order -- stored once per (row, column
+// tile), and the bf16 copy of the stream through the staging patches (16-byte stores).  `lds` must be free (a barrier
+// behind the K loop) and hold >= 96 KiB + 8 KiB.
+constexpr int LN_RED_OFF = 96 * 1024;
+
+template <int FM, int FN, int RG>
+__device__ __forceinline__ void resid_stats_epilogue(const Epi& e, f32x4 (&acc)[FM][FN], const f32x4 (*pre)[FN], int row0,
+                                                     int col0, int lane, int M, int N, char* lds, int wave, int grp,
+                                                     int wc, int tile_n, int stg_bytes) {
+    const int g = lane >> 4, li = lane & 15;
+    float* red = reinterpret_cast<float*>(lds + LN_RED_OFF);        // [2 groups][4 waves][FM * 16 rows][2]
+    f32x4 bias[FN];
+    int col[FN];
+    bool cok[FN];
+#pragma unroll
+    for (int b = 0; b < FN; ++b) {
+        const int c = col0 + b * 16 + g * 4;
+        cok[b] = c + 3 < N;
+        col[b] = cok[b] ? c : N - 4;
+        bias[b] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + col[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+        const int row_raw = row0 + a * 16 + li;
+        const bool rok = row_raw < M;
+        const int row = rok ? row_raw : M - 1;
+        const float rs = e.rowscale ? e.rowscale[row / e.rows_per_scale] : 1.f;
+        const float* add = e.resid ? e.resid + (size_t)row * e.ldo
+                                   : (e.pos ? e.pos + (size_t)(row % e.pos_rows) * e.ldo : nullptr);
+        float* o = (float*)e.out + (size_t)row * e.ldo;
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            f32x4 ad;
+            if (pre) ad = pre[a][b];
+            else ad = add ? *reinterpret_cast<const f32x4*>(add + col[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = ad + (acc[a][b] + bias[b]) * rs;
+            acc[a][b] = v;
+            if (VP_ST_OK(rok && cok[b])) *reinterpret_cast<f32x4*>(o + col[b]) = v;
+            if (cok[b]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sum += v[r];
+                    sq = __builtin_fmaf(v[r], v[r], sq);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sq += __shfl_xor(sq, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (g == 0) {
+            float* r = red + (((grp * 4 + wc) * FM * 16) + a * 16 + li) * 2;
+            r[0] = sum;
+            r[1] = sq;
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    {
+        const int r = wc * 64 + lane;            // the four waves of a row group share its FM * 16 rows
+        if (r < FM * 16 && row0 + r < M) {
+            float sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* p = red + (((grp * 4 + w) * FM * 16) + r) * 2;
+                sum += p[0];
+                sq += p[1];
+            }
+            float2* dst = reinterpret_cast<float2*>(e.ln_stats_out) + (size_t)(row0 + r) * e.ln_slots + tile_n;
+            *dst = float2{sum, sq};
+        }
+    }
+    Epi e2 = e;
+    e2.out = e.out2;
+    e2.row_div = 0;
+    run_epilogue_staged<VP_EPI_BF16, FM, FN, RG, true>(e2, acc, row0, col0, lane, M, N, lds + wave * stg_bytes);
 }
 
 template <int EPI>
@@ -1058,6 +1216,14 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
             store_rowsum(rowsum, rhi, i0 + grp * 128, 4 + wc, true, lane, M);
         }
     }
+    if constexpr (EPI == VP_EPI_RESID_F32 && !SPLIT3 && !GY) {
+        if (e.ln_stats_out) {
+            __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free
+            resid_stats_epilogue<8, 4, 4>(e, acc, nullptr, i0 + grp * 128, j0 + wc * 64, lane, M, N, &lds[0][0][0], wave,
+                                          grp, wc, j0 / T2, STG_BYTES);
+            return;
+        }
+    }
     run_epilogue<EPI, 8, 4>(e, acc, i0 + grp * 128, j0 + wc * 64, lane, M, N, slice);
 }
 
@@ -1384,10 +1550,20 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
             store_rowsum(rowsum, r1, i0 + grp * 96, 3 + rs_a1, rs_a1 < 3, lane, M);
         }
     }
-    if constexpr (EPI == VP_EPI_RESID_F32)
+    if constexpr (EPI == VP_EPI_RESID_F32) {
+        if constexpr (!ROUTE && !KMAP && !SPLIT3) {
+            if (e.ln_stats_out) {
+                __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free
+                resid_stats_epilogue<6, NU, 3>(e, acc, pre, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, &lds[0][0], wave,
+                                               grp, wc, j0 / TN, 48 * (NU * 32 + 16));
+                VP_CLK_FINAL("gemm192", work);
+                return;
+            }
+        }
         run_epilogue<EPI, 6, NU>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, slice, pre);
-    else
+    } else {
         run_epilogue<EPI, 6, NU>(e, acc, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, slice);
+    }
     VP_CLK_FINAL("gemm192", work);
 }
 
@@ -1893,6 +2069,11 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
     }
 }
 
+inline int ln_slots_of(int N, int tile_mode) {
+    const int w = tile_mode == 2 ? T2 : tile_mode == 3 ? T3 : tile_mode == 6 ? 128 : 0;
+    return w ? (N + w - 1) / w : 0;
+}
+
 inline int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -1919,6 +2100,24 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
     Epi e{a->epilogue, a->out, a->ldo, a->out2, a->bias, a->resid, a->rowscale, a->rows_per_scale,
           a->aux, a->ldaux, a->pos, a->pos_rows, a->colscale,
           a->out_row_div, a->out_row_hi, a->out_row_lo, a->out_row_off, a->split_stride};
+    e.ln_stats = a->ln_stats;
+    e.ln_stats_out = a->ln_stats_out;
+    e.ln_slots = a->ln_slots;
+    e.ln_inv_n = 1.0f / (float)a->K;
+    e.ln_eps = a->ln_eps;
+    if (a->ln_stats) {
+        // consumer of a folded LayerNorm: the reduction runs over the normalised channels
+        if ((a->epilogue != VP_EPI_BF16 && a->epilogue != VP_EPI_GELU) || !a->colscale || !a->bias || a->ln_slots < 1 ||
+            a->tile_mode == 5 || a->out_row_div > 0 || XK)
+            return VP_ERR_UNSUPPORTED;
+    }
+    if (a->ln_stats_out) {
+        // producer: the kernels whose column waves share their rows, on an explicit tile schedule (it fixes ln_slots)
+        if (a->epilogue != VP_EPI_RESID_F32 || !a->out2 || XK || a->out_row_div > 0 || ((a->N | a->ldo) & 7) != 0 ||
+            (a->tile_mode != 2 && a->tile_mode != 3 && a->tile_mode != 6) ||
+            a->ln_slots != ln_slots_of(a->N, a->tile_mode))
+            return VP_ERR_UNSUPPORTED;
+    }
     const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
     const int nk = a->K / BK;
@@ -2217,6 +2416,8 @@ int launch_split3(const vp_gemm_args* a, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int vp_gemm_ln_slots(int N, int tile_mode) { return ln_slots_of(N, tile_mode); }
 
 extern "C" int vp_gemm_bf16(const vp_gemm_args* a, hipStream_t stream) {
     VP_CHECK_ARG(a && a->x && a->y && a->out);

@@ -327,6 +327,35 @@ int static_scratch(float** out) {
     return VP_OK;
 }
 
+// Folded weights of a Linear behind a LayerNorm: one workgroup per output row n.
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias,
+                                                              bf16* __restrict__ Wg, float* __restrict__ s_out,
+                                                              float* __restrict__ c_out, int K) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* w = W + (size_t)n * K;
+    float s = 0.f, c = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float wk = w[k];
+        const bf16 r = (bf16)(wk * gamma[k]);
+        Wg[(size_t)n * K + k] = r;
+        s += (float)r;
+        c = __builtin_fmaf(wk, beta[k], c);
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if (lane == 0) {
+        red[0][wave] = s;
+        red[1][wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_out[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        c_out[n] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + (bias ? bias[n] : 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int vp_layernorm_bwd_blocks(int M, int E, size_t workspace_floats) {
@@ -445,4 +474,11 @@ extern "C" int vp_layernorm_bwd_static(const void* dy_bf16, const float* x, cons
     // only, so nothing of an earlier call has to be cleared
     return vp_layernorm_bwd(dy_bf16, x, mean, rstd, gamma, dres, dx, dxb_bf16, rowscale, rows_per_scale, dgamma, dbeta,
                             dcolsum, M, E, ws, (size_t)VP_LN_STATIC_MAX_BLOCKS * 3 * VP_LN_STATIC_MAX_E, stream);
+}
+
+extern "C" int vp_ln_fold_weights(const float* W, const float* gamma, const float* beta, const float* bias, void* Wg,
+                                  float* s, float* c, int N, int K, hipStream_t stream) {
+    VP_CHECK_ARG(W && gamma && beta && Wg && s && c && N > 0 && K > 0);
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3(N), dim3(256), 0, stream, W, gamma, beta, bias, (bf16*)Wg, s, c, K);
+    VP_LAUNCH_RET();
 }

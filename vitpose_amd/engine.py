@@ -307,8 +307,13 @@ class VitRunner:
 
     # -- forward --
     def record_forward(self, plan: Plan, ws: Workspace, img: torch.Tensor, B: int, training: bool,
-                       dp: Optional[torch.Tensor] = None, tokens_f32: Optional[torch.Tensor] = None):
-        """img [B,C,H,W] f32 -> returns the final token-major bf16 feature [B*T][E]."""
+                       dp: Optional[torch.Tensor] = None, tokens_f32: Optional[torch.Tensor] = None,
+                       fold_ln: bool = False):
+        """img [B,C,H,W] f32 -> returns the final token-major bf16 feature [B*T][E].
+        fold_ln (evaluation only; the caller keeps the folded weights current with ensure_ln_fold): norm1 / norm2 of
+        every Block are folded into the Linear behind them (see record_forward_folded)."""
+        if fold_ln and not training and self.ln_fold_supported():
+            return self.record_forward_folded(plan, ws, img, B, tokens_f32)
         E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
         H, W = self.img_hw
         col = ws.bf16('pe_col', M, self.Kpe)
@@ -356,6 +361,86 @@ class VitRunner:
             mean, rstd = ws.f32('mean_l', M), ws.f32('rstd_l', M)
             plan.layernorm_fwd(x, self.w('last_norm.weight'), self.w('last_norm.bias'), feat, tokens_f32,
                                mean if training else None, rstd if training else None, M, E)
+        else:
+            plan.cast_f32_bf16(x, feat, M * E)
+            if tokens_f32 is not None:
+                plan.strided_cast(x, tokens_f32, (1, 1, 1, M * E), (0, 0, 0, 1))
+        self._x_last = x
+        return feat
+
+    # -- evaluation forward with the Blocks' LayerNorms folded into qkv / fc1 --
+    def ln_fold_supported(self):
+        """The routed FFN of ViTMoE keeps the plain path."""
+        return not self.part
+
+    def _fold_buffers(self):
+        """Folded weights of every Block's qkv and fc1 (bf16 W diag(gamma)), their column sums s and shifted biases
+        c = W beta + b; one prep plan that rebuilds all of them from the f32 masters."""
+        if getattr(self, '_fold', None) is None:
+            E, Hd, dev = self.E, self.hidden, self.store.device
+            rows = 3 * E + Hd
+            fw = torch.empty(self.depth, rows, E, dtype=torch.bfloat16, device=dev)
+            fs = torch.empty(self.depth, rows, dtype=torch.float32, device=dev)
+            fc = torch.empty(self.depth, rows, dtype=torch.float32, device=dev)
+            prep = Plan()
+            for i in range(self.depth):
+                b = f'blocks.{i}.'
+                for r0, n, lin, norm in ((0, 3 * E, 'attn.qkv', 'norm1'), (3 * E, Hd, 'mlp.fc1', 'norm2')):
+                    bias = self.w(b + lin + '.bias') if self.has(b + lin + '.bias') else None
+                    prep.ln_fold_weights(self.w(b + lin + '.weight'), self.w(b + norm + '.weight'), self.w(b + norm + '.bias'),
+                                         bias, fw[i, r0:r0 + n], fs[i, r0:r0 + n], fc[i, r0:r0 + n], n, E)
+            self._fold = (fw, fs, fc, prep)
+            self._fold_version = None
+        return self._fold
+
+    def ensure_ln_fold(self, weights_version):
+        """Rebuild the folded weights when the f32 masters have changed since they were built (2 x depth small launches:
+        once per weight version, not per forward pass)."""
+        if getattr(self, '_fold', None) is not None and self._fold_version != weights_version:
+            self._fold[3].run()
+            self._fold_version = weights_version
+
+    def record_forward_folded(self, plan: Plan, ws: Workspace, img: torch.Tensor, B: int,
+                              tokens_f32: Optional[torch.Tensor] = None):
+        """Evaluation forward without the Blocks' LayerNorm launches (vit.py:137-140: norm1 feeds attn.qkv only,
+        norm2 feeds mlp.fc1 only).  With W' = W diag(gamma):  LN(x) W^T + b = rstd (x W'^T - mean s) + c.  Every GEMM
+        that writes the residual stream (patch embedding, proj, fc2) also writes its bf16 copy and per-row sums / sums
+        of squares per column tile; qkv and fc1 read that copy against the folded weights and finish the
+        normalisation in their epilogues.  The final LayerNorm (its consumer is the head) stays a launch."""
+        E, T, M, Hd = self.E, self.T, B * self.T, self.hidden
+        H, W = self.img_hw
+        fw, fs, fc, _ = self._fold_buffers()
+        RES = _lib.VP_EPI_RESID_F32
+        col = ws.bf16('pe_col', M, self.Kpe)
+        plan.patch_im2col(img, col, B, self.C, H, W, self.patch, self.stride, self.pad)
+        slots_max = (E + 127) // 128
+        xs = [(ws.f32('x_a', M, E), ws.bf16('xb_a', M, E), ws.f32('xst_a', M, slots_max, 2)),
+              (ws.f32('x_b', M, E), ws.bf16('xb_b', M, E), ws.f32('xst_b', M, slots_max, 2))]
+        x, xb, st = xs[0]
+        slots = plan.gemm(col, self.h('patch_embed.proj.weight'), x, M, E, self.Kpe, ldx=self.Kpe, ldy=self.Kpe, ldo=E,
+                          epilogue=RES, bias=self.w('patch_embed.proj.bias'), pos=self.pos_comb, pos_rows=T,
+                          out2=xb, ln_stats_out=st)
+        for i in range(self.depth):
+            b = f'blocks.{i}.'
+            last = i == self.depth - 1
+            qkv = ws.bf16('qkv', M, 3 * E)
+            plan.gemm(xb, fw[i, :3 * E], qkv, M, 3 * E, E, ldx=E, ldy=E, ldo=3 * E, colscale=fs[i, :3 * E],
+                      bias=fc[i, :3 * E], ln_stats=(st, slots))
+            ao = ws.bf16('ao', M, E)
+            plan.attention_fwd(qkv, ao, None, B, self.heads, self.d, T, self.scale)
+            xm, xmb, stm = xs[1]
+            slots_m = plan.gemm(ao, self.h(b + 'attn.proj.weight'), xm, M, E, E, ldx=E, ldy=E, ldo=E, epilogue=RES,
+                                bias=self.w(b + 'attn.proj.bias'), resid=x, out2=xmb, ln_stats_out=stm)
+            hact = ws.bf16('h', M, Hd)
+            plan.gemm(xmb, fw[i, 3 * E:], hact, M, Hd, E, ldx=E, ldy=E, ldo=Hd, epilogue=_lib.VP_EPI_GELU,
+                      colscale=fs[i, 3 * E:], bias=fc[i, 3 * E:], ln_stats=(stm, slots_m))
+            # (the last Block's output goes to the final LayerNorm launch: no copy, no statistics)
+            slots = plan.gemm(hact, self.h(b + 'mlp.fc2.weight'), x, M, E, Hd, ldx=Hd, ldy=Hd, ldo=E, epilogue=RES,
+                              bias=self.w(b + 'mlp.fc2.bias'), resid=xm, out2=None if last else xb,
+                              ln_stats_out=None if last else st)
+        feat = ws.bf16('feat', M, E)
+        if self.cfg.get('last_norm', True):
+            plan.layernorm_fwd(x, self.w('last_norm.weight'), self.w('last_norm.bias'), feat, tokens_f32, None, None, M, E)
         else:
             plan.cast_f32_bf16(x, feat, M * E)
             if tokens_f32 is not None:

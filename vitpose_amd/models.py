@@ -1191,6 +1191,9 @@ class TopDown(nn.Module):
 
     def _exact(self):
         """test_cfg['fp32_exact'] (extension): evaluate at the reference's fp32 accuracy instead of bf16."""
+        if self._engine is not None:
+            # test_cfg['fold_layernorm'] (extension, bf16 evaluation only): norm1 / norm2 folded into qkv / fc1
+            self._engine.fold_layernorm = bool((self.test_cfg or {}).get('fold_layernorm', False))
         return bool((self.test_cfg or {}).get('fp32_exact', False))
 
     def _infer_heatmap(self, img, flip_pairs=None, img_metas=None):

@@ -226,15 +226,29 @@ class Plan:
              epilogue=_lib.VP_EPI_BF16, out2=None, bias=None, colscale=None, resid=None,
              rowscale=None, rows_per_scale=0, aux=None, ldaux=0, pos=None, pos_rows=0, split_k=1,
              row_map=None, split_stride=0, tail_force=False, tile_mode=0, route=None, gather16=None,
-             split3=False, pair_act=0):
+             split3=False, pair_act=0, ln_stats=None, ln_stats_out=None, ln_eps=1e-6):
         """gather16 = (H, W, C): y is a transposed conv's output-grid gradient [B*2H*2W][C] and the Y operand its
         reduction-major 16-tap gather (see vp_gemm_args in the header).
         route = (expert [images] int32, delta [experts] int64, bias_delta [experts] int64 or None, split):
         per-image routing of the Y operand (mixture-of-experts FFN; see vp_gemm_args in the header).
         split3: x and y are hi / lo pair arrays (rows of 2 K bf16) and the product is fp32-accurate (hi*hi + hi*lo +
         lo*hi per K step in one launch); epilogue VP_EPI_F32 / VP_EPI_RESID_F32 / VP_EPI_PAIR (out = pair array of
-        act(acc * colscale + bias), pair_act 0 none / 1 exact GELU / 2 ReLU)."""
+        act(acc * colscale + bias), pair_act 0 none / 1 exact GELU / 2 ReLU).
+        LayerNorm fold (evaluation; vp_gemm_args.ln_stats in the header): ln_stats_out = f32 [M][slots >= ceil(N / 128)][2]
+        makes a VP_EPI_RESID_F32 launch a PRODUCER (out2 = bf16 copy of the stream; returns the number of statistics
+        slots per row its tile schedule writes); ln_stats = (that tensor, slots) makes a VP_EPI_BF16 / GELU launch the
+        CONSUMER (x = the bf16 copy, y = folded weights, colscale = s, bias = c)."""
         a = GemmArgs()
+        if ln_stats is not None:
+            _chk(ln_stats[0], torch.float32, 'ln_stats')
+            a.ln_stats, a.ln_slots, a.ln_eps = ln_stats[0].data_ptr(), int(ln_stats[1]), ln_eps
+            self.keep.append(ln_stats[0])
+        if ln_stats_out is not None:
+            _chk(ln_stats_out, torch.float32, 'ln_stats_out')
+            if out2 is None or ln_stats_out.numel() < 2 * M * ((N + 127) // 128):
+                raise ValueError('a folded-LayerNorm producer needs out2 and statistics for ceil(N / 128) slots per row')
+            a.ln_stats_out = ln_stats_out.data_ptr()
+            self.keep.append(ln_stats_out)
         a.split3, a.pair_act = int(split3), int(pair_act)
         if gather16 is not None:
             zero = _zero_page(out.device)
@@ -269,10 +283,20 @@ class Plan:
             tw = _tail_workspace(out.device)
             a.tail_ws, a.tail_ws_bytes = tw.data_ptr(), tw.numel() * 4
             self.keep.append(tw)
+        producer = ln_stats_out is not None
+        if producer and tile_mode == 0:
+            # A producer's tile schedule fixes the order in which a row's statistics are added up, so it is chosen by
+            # the output width alone -- never by timing, never by the number of rows: an image's result must not depend
+            # on the batch around it.  192-wide tiles where they divide the width (ViTPose-S / -B), else 128-wide
+            # (ViTPose-L / -H).
+            tile_mode = 3 if N % 192 == 0 else 6
+            a.tile_mode = tile_mode
+        if producer:
+            a.ln_slots = self.L.vp_gemm_ln_slots(N, a.tile_mode)
         if (AUTOTUNE and tile_mode == 0 and epilogue != _lib.VP_EPI_SPLITK_F32 and M >= 512 and N >= 256 and K >= 256
                 and route is None):
             key = ('gemm', M, N, K, int(x_kmajor), int(y_kmajor), epilogue, resid is not None, out2 is not None,
-                   str(out.device), int(split3), int(pair_act))
+                   str(out.device), int(split3), int(pair_act), ln_stats is not None, producer)
             ov = _TUNE_OVERRIDE.get(f'{int(x_kmajor)}{int(y_kmajor)}:{epilogue}:{N}:{K}')
             if ov is not None and key not in _TUNE_CACHE:
                 _TUNE_CACHE[key] = ov
@@ -291,16 +315,20 @@ class Plan:
                     # cache-hot timing done here -- fc2 + residual 55.3 against 58.9 us -- and loses inside the step, 50.5
                     # against 49.4 us, and 2 % of the ViTPose-H evaluation pass: not offered for VP_EPI_RESID_F32.)
                     modes.append(7)
-                if (not x_kmajor and not split3 and K >= 640 and M % 192 == 0 and row_map is None and colscale is None
+                if (not x_kmajor and not split3 and K >= 512 and M % 192 == 0 and row_map is None and colscale is None
+                        and ln_stats is None and N % 8 == 0 and ldo % 8 == 0
                         and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_GELU, _lib.VP_EPI_DGELU)
                         and (M // 192) * ((N + 191) // 192) > 256):
                     modes.append(5)       # persistent 192-tile kernel: only where a workgroup gets several tiles
                 _TUNE_CACHE[key] = _pick_fastest({m: launch(m) for m in modes})
             a.tile_mode = _TUNE_CACHE[key]
+        if producer:
+            a.ln_slots = self.L.vp_gemm_ln_slots(N, a.tile_mode)
         self.tags[len(self.calls)] = (int(x_kmajor), int(y_kmajor), epilogue + (200 if split3 else 0), M, N,
                                       3 * K if split3 else K)
         self._add('vp_gemm_bf16', ctypes.byref(a),
                   keep=(a, x, y, out, out2, bias, colscale, resid, rowscale, aux, pos))
+        return a.ln_slots if producer else None
 
     def wgrad(self, x, y, out, M, N, K, *, ldx, ldy, split_k, slab, accumulate=False, tile_mode=0, gather16=None):
         """out[M][N] (f32) (+)= x^T y with x [K][M], y [K][N] (both reduction-major): the weight
@@ -439,6 +467,12 @@ class Plan:
         blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(entries[0][0].device)
         self._add('vp_layernorm_bwd_finalize', _p(blob), len(entries), E,
                   keep=(blob,) + tuple(x for e in entries for x in e))
+
+    def ln_fold_weights(self, w, gamma, beta, bias, wg, s, c, N, K):
+        """wg (bf16 [N][K]) = w * gamma, s [N] = row sums of wg, c [N] = w beta + bias (see vp_ln_fold_weights)."""
+        _chk(w, torch.float32, 'w'), _chk(wg, torch.bfloat16, 'wg'), _chk(s, torch.float32, 's'), _chk(c, torch.float32, 'c')
+        self._add('vp_ln_fold_weights', _p(w), _p(gamma), _p(beta), _p(bias), _p(wg), _p(s), _p(c), N, K,
+                  keep=(w, gamma, beta, bias, wg, s, c))
 
     def attention_fwd(self, qkv, out, lse, B, H, d, tokens, scale):
         self._add('vp_attention_fwd', _p(qkv), _p(out), _p(lse), B, H, d, tokens, scale, keep=(qkv, out, lse))

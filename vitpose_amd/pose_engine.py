@@ -48,6 +48,7 @@ class PoseEngine:
         self.ws_heads = [self.ws_train] + [Workspace(self.device) for _ in self.heads[1:]]
         self.ws_infer = Workspace(self.device)
         self.plans = {}
+        self.fold_layernorm = False    # evaluation default (TopDown sets it from test_cfg['fold_layernorm'])
         self.prep = Plan()
         self.prep.cast_f32_bf16(self.store.data, self.store.half, self.store.numel)
         self.prep_derived = Plan()  # after an optimizer step the bf16 mirror is already fresh
@@ -94,14 +95,22 @@ class PoseEngine:
         self.vit.refresh_derived()
 
     # ---- inference ----
-    def _infer_plan(self, B):
-        key = ('infer', B)
+    def _infer_plan(self, B, fold=False):
+        """The evaluation plan of batch size B.  fold = True (opt-in: `test_cfg['fold_layernorm']`, infer(fold_ln=True)):
+        VitRunner.record_forward_folded -- the GEMMs that write the residual stream also emit its bf16 copy and row
+        statistics, qkv / fc1 finish norm1 / norm2 in their epilogues, the LayerNorm launches disappear.  Measured on one
+        MI355X: ViTPose-B at batch 64 +3.5 %, ViTPose-L at 32 +4.1 %; ViTPose-S at 64 -0.9 %, ViTPose-H at 128 -6.8 % (its
+        LayerNorm launch already runs at 5 TB/s and the 256-wide tiles have no registers to spare in their epilogues),
+        ViTPose-B at batch 8 -14 % (small grids want the schedules the producers of the fold may not choose).  Not the
+        default: the plain plan is also the one whose result for an image is bit-identical at every batch size."""
+        fold = bool(fold) and self.vit.ln_fold_supported()
+        key = ('infer', B, True) if fold else ('infer', B)
         if key not in self.plans:
             ws = self.ws_infer
             H, W = self.vit.img_hw
             img = ws.f32('img', B, self.vit.C, H, W)
             plan = Plan()
-            feat = self.vit.record_forward(plan, ws, img, B, training=False)
+            feat = self.vit.record_forward(plan, ws, img, B, training=False, fold_ln=fold)
             oh, ow = self.head.out_grid
             heat = ws.f32('heat', B, self.K, oh, ow)
             self.head.record_forward(plan, ws, feat, B, False, heat)
@@ -132,19 +141,22 @@ class PoseEngine:
 
     @torch.no_grad()
     def infer(self, img: torch.Tensor, copy_out: bool = True, exact: bool = False,
-              dataset_source=None) -> torch.Tensor:
+              dataset_source=None, fold_ln: Optional[bool] = None) -> torch.Tensor:
         """img [B,3,H,W] f32 on the device -> heatmaps [B,K,4Hp,4Wp] f32 (eval-mode BN) of the main head.
         exact=True evaluates at fp32 accuracy (see _exact_plan).  dataset_source: per-image dataset indices
         (ViTMoE backbone: selects the FFN expert, vit_moe.py:98-115; None = dataset 0)."""
         B = img.shape[0]
         if B < 1:
             raise ValueError('empty batch')
-        plan, img_in, heat = self._exact_plan(B) if exact else self._infer_plan(B)
+        fold = (self.fold_layernorm if fold_ln is None else fold_ln) and not exact and self.vit.ln_fold_supported()
+        plan, img_in, heat = self._exact_plan(B) if exact else self._infer_plan(B, fold)
         if self.routed:
             self.vit.set_routing(self.ws_infer, B, dataset_source if dataset_source is not None else [0] * B)
         if exact and self._exact_version != self._weights_version:
             self.prep_exact.run()               # the pair arrays follow the f32 masters (refresh_weights bumps the version)
             self._exact_version = self._weights_version
+        if fold:
+            self.vit.ensure_ln_fold(self._weights_version)      # folded LayerNorm weights follow the f32 masters
         if img.data_ptr() != img_in.data_ptr():
             img_in.copy_(img)
         plan.run()
