@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f'{name} declared in include/vitpose_hip.h but not exported'
     assert sorted(_lib.exported_symbols()) == declared
-    assert L.vp_abi_version() == _lib.ABI_VERSION == 3 and L.vp_build_arch() == b'gfx950'
+    assert L.vp_abi_version() == _lib.ABI_VERSION == 4 and L.vp_build_arch() == b'gfx950'
 
 
 @pytest.mark.parametrize('n_in,scale,align', [(16, 4, False), (12, 4, False), (12, 2, True), (5, 3, False), (7, 1, False)])
