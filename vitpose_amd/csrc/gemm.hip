@@ -1775,39 +1775,11 @@ __device__ __forceinline__ void loaded(T& v) {
     asm volatile("" : "+v"(v));
 }
 
-// Staging of the deferred epilogue: 16 rows x 48 columns of bf16 per wave at a pitch of 112 bytes (8-byte writes in the
-// accumulator layout and 16-byte reads in the row layout are both conflict-free at that pitch)
-constexpr int PSTG_PITCH = 112, PSTG_BYTES = 16 * PSTG_PITCH;
-
-// LDS accesses of the staging patch as raw instructions: the compiler's wait-count pass cannot tell them from the
-// targets of the LDS-DMA loads in flight and would put `s_waitcnt vmcnt(0)` in front of every one of them (the whole
-// operand prefetch of the K loop would have to land first).  Program order is enough here: a wave's LDS instructions
-// execute in issue order, the patch is private to the wave, and staged_wait() stands between a read and its use.
-__device__ __forceinline__ unsigned lds_addr(const char* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void staged_read(u32x4& dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void staged_write(unsigned addr, const bf16x4& v) {
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "i"(OFF) : "memory");
-}
-__device__ __forceinline__ void staged_wait(u32x4& a, u32x4& b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(a));
-    asm volatile("" : "+v"(b));
-}
-
-template <bool XKMAJ, bool YKMAJ, int EPI, bool TWO>
+template <bool XKMAJ, bool YKMAJ, int EPI>
 __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Operand Y, int M, int N, int K,
                                                                  int tiles_n, int ntiles, Epi e) {
     static_assert(EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU || EPI == VP_EPI_DGELU, "bf16 outputs only");
-    static_assert(!TWO || EPI == VP_EPI_GELU, "only the GELU epilogue has a second output (the pre-activations)");
-    // (one allocation: three K-tile stages, then the eight staging patches of the deferred epilogue)
-    __shared__ __attribute__((aligned(16))) char lds_all[3 * STAGE3_BYTES + 8 * PSTG_BYTES];
-    char (*lds)[STAGE3_BYTES] = reinterpret_cast<char (*)[STAGE3_BYTES]>(lds_all);
+    __shared__ __attribute__((aligned(16))) char lds[3][STAGE3_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
@@ -1832,19 +1804,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
         for (int b = 0; b < 3; ++b) acc[a][b] = pacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool pending = false;
     int pi0 = 0, pj0 = 0;
-    // The pending tile leaves in STEPS of one 16-row fragment row of the wave's block (16 x 48 values; with two outputs
-    // the pre-activations and the activations of a fragment row are two steps).  A step goes through the wave's own
-    // staging patch: written in the accumulator layout (8 bytes per lane), read back one slot later as rows and stored
-    // as 16 bytes per lane -- 96 contiguous bytes per row instead of three 8-byte pieces per lane scattered over 16 rows
-    // (a third of the vector-memory instructions, each moving twice the bytes in a sixth of the address ranges).
-    constexpr int NST = TWO ? 12 : 6;
-    const unsigned stg = lds_addr(lds_all + 3 * STAGE3_BYTES + wave * PSTG_BYTES);
-    const unsigned wr_at = stg + li * PSTG_PITCH + g * 8;
-    const int id1 = lane < 32 ? 64 + lane : lane;         // second row-layout slot (lanes 0-31 only)
-    const unsigned rd0 = stg + (lane / 6) * PSTG_PITCH + (lane % 6) * 16;
-    const unsigned rd1 = stg + (id1 / 6) * PSTG_PITCH + (id1 % 6) * 16;
-    const bool second = lane < 32;
-    int off_a = 0, off_b = 0;   // element offsets of this lane's two row-layout slots in the pending tile (both outputs)
+    // per pending tile: this lane's first output element, bias of its 12 columns, pre-activation prefetch ring
+    bf16* po = nullptr;
+    bf16* po2 = nullptr;
     const bf16* paux = nullptr;
     f32x4 pbias[3];
     bf16x4 uq[6];
@@ -1852,63 +1814,41 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
     for (int i = 0; i < 6; ++i) uq[i] = bf16x4{};
 #pragma unroll
     for (int b = 0; b < 3; ++b) pbias[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool two_outputs = EPI == VP_EPI_GELU && e.out2 != nullptr;
 
     auto stage_at = [&](int unit, int si0, int sj0, int sk, int st) {
         char* dst = lds[st] + unit * UNIT_BYTES;
         if (unit < 3) stage_unit<XKMAJ>(X, si0 + unit * 64, sk, dst, wave, lane);
         else stage_unit<YKMAJ>(Y, sj0 + (unit - 3) * 64, sk, dst, wave, lane);
     };
-    auto load_u = [&](bf16x4& dst, int a, int b) {       // pre-activations of fragment (a, b) of the pending tile
+    auto load_u = [&](bf16x4& dst, int f) {       // pre-activations of fragment f = (a, b) of the pending tile
+        const int a = f / 3, b = f - a * 3;
         gload_raw(dst, paux + (size_t)(a * 16) * e.ldaux + b * 16);
     };
-    // Slot S of the pending tile (S < 0: nothing): stores step S - 1 from the staging patch and computes step S into
-    // it.  Only tiles that lie wholly inside the output are deferred, so every store is unconditional and the number of
-    // vector-memory operations a slot issues is a compile-time constant (the counted waits of the K loop rely on it):
-    // 2 stores for S >= 1, and with VP_EPI_DGELU 3 loads (the pre-activations of step S + 2) for S + 2 < NST.
-    auto slot = [&](auto stag) {
-        constexpr int S = decltype(stag)::value;
-        if constexpr (S >= 0) {
-            constexpr int a = TWO ? S / 2 : S;
-            constexpr bool act = !TWO || (S & 1);              // TWO: even steps carry the pre-activations
-            auto value = [&](auto btag) {                      // fragment (a, b) of step S as it leaves
-                constexpr int b = decltype(btag)::value;
-                f32x4 v = pacc[a < 6 ? a : 0][b];
-                if constexpr (EPI == VP_EPI_DGELU) {
-                    loaded(uq[(a & 1) * 3 + b]);
-                    const bf16x4 u = uq[(a & 1) * 3 + b];
-                    if constexpr (a + 2 < 6) load_u(uq[(a & 1) * 3 + b], a + 2, b);
-                    v *= gelu_erf_grad(__builtin_convertvector(u, f32x4));
-                } else {
-                    if constexpr (S == 0) loaded(pbias[b]);
-                    v = v + pbias[b];
-                    if constexpr (EPI == VP_EPI_GELU && act) v = gelu_erf(v);
+    // Epilogue of fragment F of the pending tile (F < 0: nothing).  Only tiles that lie wholly inside the output are
+    // deferred, so every store below is unconditional: the number of vector-memory operations a slot issues is a
+    // compile-time constant (the counted waits of the K loop rely on it).
+    auto slot = [&](auto ftag) {
+        constexpr int F = decltype(ftag)::value;
+        if constexpr (F >= 0) {
+            constexpr int a = F / 3, b = F % 3;
+            f32x4 v = pacc[a][b];
+            bf16* o = po + (size_t)(a * 16) * e.ldo + b * 16;
+            if constexpr (EPI == VP_EPI_DGELU) {
+                loaded(uq[F % 6]);
+                const bf16x4 u = uq[F % 6];
+                if constexpr (F + 6 < 18) load_u(uq[F % 6], F + 6);
+                v *= gelu_erf_grad(__builtin_convertvector(u, f32x4));
+            } else {
+                if constexpr (a == 0) loaded(pbias[b]);
+                v = v + pbias[b];
+                if constexpr (EPI == VP_EPI_GELU) {
+                    if (two_outputs)
+                        *reinterpret_cast<bf16x4*>(po2 + (size_t)(a * 16) * e.ldo + b * 16) = pack4(v[0], v[1], v[2], v[3]);
+                    v = gelu_erf(v);
                 }
-                return pack4(v[0], v[1], v[2], v[3]);
-            };
-            // order: the staged rows of step S - 1 are requested, fragment 0 of step S is computed while they travel,
-            // they leave, and only then is the patch overwritten (one fragment at a time: few registers live at once)
-            u32x4 r0v = u32x4{0, 0, 0, 0}, r1v = u32x4{0, 0, 0, 0};
-            if constexpr (S >= 1) {
-                staged_read(r0v, rd0);
-                staged_read(r1v, rd1);
             }
-            bf16x4 o0 = bf16x4{};
-            if constexpr (S < NST) o0 = value(ic<0>{});
-            if constexpr (S >= 1) {
-                constexpr int pa = TWO ? (S - 1) / 2 : S - 1;
-                constexpr bool pact = !TWO || ((S - 1) & 1);
-                bf16* base = (bf16*)(pact ? e.out : e.out2) + (size_t)(pa * 16) * e.ldo;
-                staged_wait(r0v, r1v);
-                *reinterpret_cast<u32x4*>(base + off_a) = r0v;
-                if (second) *reinterpret_cast<u32x4*>(base + off_b) = r1v;
-            }
-            if constexpr (S < NST) {
-                staged_write<0>(wr_at, o0);
-                const bf16x4 o1 = value(ic<1>{});
-                staged_write<32>(wr_at, o1);
-                const bf16x4 o2 = value(ic<2>{});
-                staged_write<64>(wr_at, o2);
-            }
+            *reinterpret_cast<bf16x4*>(o) = pack4(v[0], v[1], v[2], v[3]);
         }
     };
 
@@ -1928,16 +1868,14 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
         int ni0 = i0, nj0 = j0;
         if (has_next) coords(tn, ni0, nj0);
         int u = 0;
-        // One K tile; S0 / S1 = slots of the pending tile run in its two phases.  Vector-memory operations between
+        // One K tile; S0 / S1 = pending-tile fragments written in its two phases.  Vector-memory operations between
         // two counted waits, in issue order: 3 LDS-DMA, slot S0, slot S1, 3 LDS-DMA -- everything older (the LDS-DMA
         // loads of K tile u + 1 among it) has landed once at most that many operations are outstanding (loads and
         // stores of a wave complete in issue order on this target).
         auto iter = [&](auto s0tag, auto s1tag) {
             constexpr int S0 = decltype(s0tag)::value, S1 = decltype(s1tag)::value;
-            constexpr auto nops = [](int S) {
-                return (S >= 1 ? 2 : 0) + (EPI == VP_EPI_DGELU && S >= 0 && S + 2 < NST ? 3 : 0);
-            };
-            constexpr int NOPS = nops(S0) + nops(S1);
+            constexpr int NSLOT = (S0 >= 0) + (S1 >= 0);
+            constexpr int NLOADS = EPI == VP_EPI_DGELU ? (S0 >= 0 && S0 + 6 < 18) + (S1 >= 0 && S1 + 6 < 18) : 0;
             int si0 = i0, sj0 = j0, sk = (u + 2) * BK;        // K tile u + 2, possibly of the next output tile
             if (u + 2 >= nk) {
                 if (has_next) { si0 = ni0; sj0 = nj0; sk = (u + 2 - nk) * BK; }
@@ -1980,7 +1918,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
             stage_at(2, si0, sj0, sk, nxt2);
             stage_at(4, si0, sj0, sk, nxt2);
             stage_at(5, si0, sj0, sk, nxt2);
-            wait_vm<6 + NOPS>();
+            if (EPI == VP_EPI_GELU && two_outputs) wait_vm<6 + 2 * NSLOT>();
+            else wait_vm<6 + NSLOT + NLOADS>();
             __builtin_amdgcn_s_barrier();
             if constexpr (XKMAJ) lds_fence(xf);
             __builtin_amdgcn_s_setprio(1);
@@ -1999,23 +1938,15 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
         };
         if (pending) {
             iter(ic<-1>{}, ic<-1>{});      // the loads issued at the tile switch land behind this K tile's wait
-            if constexpr (TWO) {
-                iter(ic<0>{}, ic<1>{});
-                iter(ic<2>{}, ic<3>{});
-                iter(ic<4>{}, ic<5>{});
-                iter(ic<6>{}, ic<7>{});
-                iter(ic<8>{}, ic<9>{});
-                iter(ic<10>{}, ic<11>{});
-                iter(ic<12>{}, ic<-1>{});
-            } else {
-                iter(ic<0>{}, ic<-1>{});
-                iter(ic<1>{}, ic<-1>{});
-                iter(ic<2>{}, ic<-1>{});
-                iter(ic<3>{}, ic<-1>{});
-                iter(ic<4>{}, ic<-1>{});
-                iter(ic<5>{}, ic<-1>{});
-                iter(ic<6>{}, ic<-1>{});
-            }
+            iter(ic<0>{}, ic<1>{});
+            iter(ic<2>{}, ic<3>{});
+            iter(ic<4>{}, ic<5>{});
+            iter(ic<6>{}, ic<7>{});
+            iter(ic<8>{}, ic<9>{});
+            iter(ic<10>{}, ic<11>{});
+            iter(ic<12>{}, ic<13>{});
+            iter(ic<14>{}, ic<15>{});
+            iter(ic<16>{}, ic<17>{});
         }
 #pragma unroll 1
         while (u < nk) iter(ic<-1>{}, ic<-1>{});
@@ -2040,16 +1971,16 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192p_kernel(Operand X, Oper
         if (!has_next) break;
         if (pending) {
             // M is a multiple of the tile height (checked by the launcher): every row exists
-            const int row0 = pi0 + grp * 96, col0 = pj0 + wc * 48;
-            off_a = (row0 + lane / 6) * e.ldo + col0 + (lane % 6) * 8;      // (M * ldo < 2^31: checked by the launcher)
-            off_b = (row0 + id1 / 6) * e.ldo + col0 + (id1 % 6) * 8;
+            const int row = pi0 + grp * 96 + li, col = pj0 + wc * 48 + g * 4;
+            po = (bf16*)e.out + (size_t)row * e.ldo + col;
+            if constexpr (EPI == VP_EPI_GELU) po2 = two_outputs ? (bf16*)e.out2 + (size_t)row * e.ldo + col : nullptr;
             if constexpr (EPI == VP_EPI_DGELU) {
-                paux = (const bf16*)e.aux + (size_t)(row0 + li) * e.ldaux + col0 + g * 4;
+                paux = (const bf16*)e.aux + (size_t)row * e.ldaux + col;
 #pragma unroll
-                for (int f = 0; f < 6; ++f) load_u(uq[f], f / 3, f % 3);
+                for (int f = 0; f < 6; ++f) load_u(uq[f], f);
             } else if (e.bias) {
 #pragma unroll
-                for (int b = 0; b < 3; ++b) gload_raw(pbias[b], e.bias + col0 + g * 4 + b * 16);
+                for (int b = 0; b < 3; ++b) gload_raw(pbias[b], e.bias + col + b * 16);
             }
         }
         t = tn;
@@ -2208,23 +2139,19 @@ int launch_layout(const vp_gemm_args* a, hipStream_t st) {
         // persistent 192-tile kernel (epilogue of tile i under the K loop of tile i + 1): forward / data-gradient
         // products with a bf16 output, more than one round of tiles, at least 9 K tiles
         const int tm5 = (a->M + T3 - 1) / T3, tn5 = (a->N + T3 - 1) / T3, nt5 = tm5 * tn5;
-        // (8 K tiles: one without a slot, then the 7 (13 with two outputs, two per K tile) slots of the pending tile;
-        //  rows of the output 16-byte aligned: the deferred tile is stored as 16 bytes per lane)
-        if (XK || split > 1 || nk < 8 || a->out_row_div > 0 || a->colscale || a->M % T3 != 0 || a->N < 4 ||
-            ((a->N | a->ldo) & 7) != 0 || (long long)a->M * a->ldo >= (1LL << 31))
+        if (XK || split > 1 || nk < 10 || a->out_row_div > 0 || a->colscale || a->M % T3 != 0 || a->N < 4)
             return VP_ERR_UNSUPPORTED;
         const int grid5 = nt5 < num_cus() ? nt5 : num_cus();
         if constexpr (!XK) {
-#define VP_GEMM5_CASE(EPI, TWO)                                                                                    \
-    hipLaunchKernelGGL((gemm192p_kernel<false, YK, EPI, TWO>), dim3(grid5), dim3(T2_THREADS), 0, st, X, Y, a->M, \
-                       a->N, a->K, tn5, nt5, e)
+#define VP_GEMM5_CASE(EPI)                                                                                    \
+    case EPI:                                                                                                 \
+        hipLaunchKernelGGL((gemm192p_kernel<false, YK, EPI>), dim3(grid5), dim3(T2_THREADS), 0, st, X, Y, a->M, \
+                           a->N, a->K, tn5, nt5, e);                                                          \
+        break;
             switch (a->epilogue) {
-                case VP_EPI_BF16: VP_GEMM5_CASE(VP_EPI_BF16, false); break;
-                case VP_EPI_GELU:
-                    if (a->out2) VP_GEMM5_CASE(VP_EPI_GELU, true);
-                    else VP_GEMM5_CASE(VP_EPI_GELU, false);
-                    break;
-                case VP_EPI_DGELU: VP_GEMM5_CASE(VP_EPI_DGELU, false); break;
+                VP_GEMM5_CASE(VP_EPI_BF16)
+                VP_GEMM5_CASE(VP_EPI_GELU)
+                VP_GEMM5_CASE(VP_EPI_DGELU)
                 default:
                     return VP_ERR_UNSUPPORTED;
             }

@@ -315,8 +315,8 @@ class Plan:
                     # cache-hot timing done here -- fc2 + residual 55.3 against 58.9 us -- and loses inside the step, 50.5
                     # against 49.4 us, and 2 % of the ViTPose-H evaluation pass: not offered for VP_EPI_RESID_F32.)
                     modes.append(7)
-                if (not x_kmajor and not split3 and K >= 512 and M % 192 == 0 and row_map is None and colscale is None
-                        and ln_stats is None and N % 8 == 0 and ldo % 8 == 0
+                if (not x_kmajor and not split3 and K >= 640 and M % 192 == 0 and row_map is None and colscale is None
+                        and ln_stats is None
                         and epilogue in (_lib.VP_EPI_BF16, _lib.VP_EPI_GELU, _lib.VP_EPI_DGELU)
                         and (M // 192) * ((N + 191) // 192) > 256):
                     modes.append(5)       # persistent 192-tile kernel: only where a workgroup gets several tiles
