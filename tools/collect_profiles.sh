@@ -32,6 +32,7 @@ run infer_B64 30 5 --mode infer --model B --batch 64
 run train_L32 10 4 --model L --batch 32
 run infer_H128 10 4 --mode infer --model H --batch 128
 run infer_B64_exact 20 5 --mode infer --model B --batch 64 --exact
+run infer_B64_fold 30 5 --mode infer --model B --batch 64 --fold-ln
 pmc train_B train_B64
 pmc infer_H128 infer_H128 --mode infer --model H --batch 128
 pmc infer_B64 infer_B64 --mode infer --model B --batch 64
