@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """Times vp_layernorm_fwd (and vp_layernorm_bwd) at the ViTPose-B training shape (12288 x 768) and the ViTPose-H
 inference shape (24576 x 1280): `reps` launches in a row over a ring of input / output buffers larger than the
-Infinity Cache (every launch reads and writes cold lines, as inside a step), one event pair around the lot.
-VP_LN_FWD_BLOCKS=<n> (read by the library at its first call) sets the forward grid for a sweep."""
+Infinity Cache (every launch reads and writes cold lines, as inside a step), one event pair around the lot."""
 import os
 import sys
 
@@ -34,8 +33,7 @@ for M, E in ((12288, 768), (24576, 1280), (6144, 1024)):
     err = (ys[-1].float() - ref).abs().max().item()
     nbytes = M * E * 6 + M * 8
     print(f'ln_fwd {M} x {E}: median {ts[len(ts) // 2]:.2f} us per launch (min {ts[0]:.2f}) = '
-          f'{nbytes / ts[len(ts) // 2] / 1e6:.2f} TB/s; max abs err vs torch {err:.3e}; grid cap '
-          f"{os.environ.get('VP_LN_FWD_BLOCKS', 'default')}")
+          f'{nbytes / ts[len(ts) // 2] / 1e6:.2f} TB/s; max abs err vs torch {err:.3e}')
     # backward: dy (bf16), x, residual gradient in, dx + bf16 copy out: (2 + 4 + 4) E in, (4 + 2) E out per row
     rb = max(4, (600 << 20) // (M * E * 16))
     dys = [ys[i % len(ys)] for i in range(rb)]
