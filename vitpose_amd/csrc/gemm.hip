@@ -23,6 +23,12 @@
 #include "common.h"
 #include "vitpose_hip.h"
 
+#ifdef VP_ABLATE_NOFOLD   /* A/B build: the kernels without the folded-LayerNorm epilogue paths */
+#define VP_FOLD(x) false
+#else
+#define VP_FOLD(x) __builtin_expect(!!(x), 0)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
@@ -318,7 +324,7 @@ template <int EPI, int FM, int FN>
 __device__ __forceinline__ void run_epilogue(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
                                              int M, int N, int slice = 0, const f32x4 (*pre)[FN] = nullptr) {
     if constexpr (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU) {
-        if (e.ln_stats) return run_epilogue_impl<EPI, FM, FN, true>(e, acc, row0, col0, lane, M, N, slice, pre);
+        if (VP_FOLD(e.ln_stats)) return run_epilogue_impl<EPI, FM, FN, true>(e, acc, row0, col0, lane, M, N, slice, pre);
     }
     run_epilogue_impl<EPI, FM, FN, false>(e, acc, row0, col0, lane, M, N, slice, pre);
 }
@@ -430,7 +436,7 @@ template <int EPI, int FM, int FN = 4, int RG = 4, bool RAW = false>
 __device__ __forceinline__ void run_epilogue_staged(const Epi& e, f32x4 (&acc)[FM][FN], int row0, int col0, int lane,
                                                     int M, int N, char* stg) {
     if constexpr (!RAW && (EPI == VP_EPI_BF16 || EPI == VP_EPI_GELU)) {
-        if (e.ln_stats) return run_epilogue_staged_impl<EPI, FM, FN, RG, false, true>(e, acc, row0, col0, lane, M, N, stg);
+        if (VP_FOLD(e.ln_stats)) return run_epilogue_staged_impl<EPI, FM, FN, RG, false, true>(e, acc, row0, col0, lane, M, N, stg);
     }
     run_epilogue_staged_impl<EPI, FM, FN, RG, RAW, false>(e, acc, row0, col0, lane, M, N, stg);
 }
@@ -1217,7 +1223,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(Operand X, Opera
         }
     }
     if constexpr (EPI == VP_EPI_RESID_F32 && !SPLIT3 && !GY) {
-        if (e.ln_stats_out) {
+        if (VP_FOLD(e.ln_stats_out)) {
             __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free
             resid_stats_epilogue<8, 4, 4>(e, acc, nullptr, i0 + grp * 128, j0 + wc * 64, lane, M, N, &lds[0][0][0], wave,
                                           grp, wc, j0 / T2, STG_BYTES);
@@ -1552,7 +1558,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm192_kernel(Operand X, Opera
     }
     if constexpr (EPI == VP_EPI_RESID_F32) {
         if constexpr (!ROUTE && !KMAP && !SPLIT3) {
-            if (e.ln_stats_out) {
+            if (VP_FOLD(e.ln_stats_out)) {
                 __builtin_amdgcn_s_barrier();              // every wave's loads have landed: LDS is free
                 resid_stats_epilogue<6, NU, 3>(e, acc, pre, i0 + grp * 96, j0 + wc * WCOLS, lane, M, N, &lds[0][0], wave,
                                                grp, wc, j0 / TN, 48 * (NU * 32 + 16));
